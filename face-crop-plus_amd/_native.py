@@ -1,0 +1,90 @@
+"""ctypes binding of the C ABI in ``include/fcp_hip.h`` (``csrc/libfcp_hip.so``).
+
+There is deliberately no fallback: if the HIP library is missing or a call
+fails, a RuntimeError is raised — the product path never runs on a CPU or an
+eager-PyTorch substitute.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
+ABI_VERSION = 1
+
+c_f32p = C.c_void_p
+_lib = None
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``fcp_conv_desc``."""
+    _fields_ = [
+        ("in_", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+        ("res1", C.c_void_p), ("res2", C.c_void_p),
+        ("n", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
+        ("cin", C.c_int32), ("in_ld", C.c_int32), ("in_up2", C.c_int32),
+        ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+        ("stride", C.c_int32), ("pad", C.c_int32),
+        ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_ld", C.c_int32),
+        ("tile_n", C.c_int32), ("cin4", C.c_int32),
+        ("act_slope", C.c_float), ("alpha", C.c_float), ("alpha2", C.c_float),
+        ("res1_pre", C.c_int32), ("res1_ld", C.c_int32), ("res1_h", C.c_int32),
+        ("res1_w", C.c_int32), ("res2_ld", C.c_int32),
+    ]
+
+
+# name -> argtypes; every function returns int (0 = ok)
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+SIGNATURES = {
+    "fcp_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P],
+    "fcp_u8_to_nhwc4_f32": [_P, _P, _L, C.POINTER(C.c_float), _F, _P],
+    "fcp_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "fcp_retina_decode": [_P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "fcp_retina_nms_select": [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
+    "fcp_retina_gather_faces": [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P],
+    "fcp_estimate_transform": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "fcp_warp_affine_u8": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+}
+EXPORTS = ["fcp_abi_version", "fcp_last_error"] + list(SIGNATURES)
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run "
+            f"`python face-crop-plus_amd/build_native.py` (needs hipcc). There is no CPU fallback.")
+    l = C.CDLL(LIB_PATH)
+    l.fcp_abi_version.restype = C.c_int
+    l.fcp_last_error.restype = C.c_char_p
+    if l.fcp_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libfcp_hip.so ABI {l.fcp_abi_version()} != expected {ABI_VERSION}; rebuild")
+    for name, args in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().fcp_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what or 'fcp_hip'} failed ({rc}): {msg}")
+
+
+def stream_ptr():
+    """Current torch HIP stream as a raw hipStream_t."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, byte_offset: int = 0):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr() + byte_offset)

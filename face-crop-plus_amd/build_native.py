@@ -1,0 +1,71 @@
+"""Compile csrc/*.hip for gfx950 into csrc/libfcp_hip.so (in-tree, so the built
+library travels with the repo snapshot to the GPU box).
+
+    python face-crop-plus_amd/build_native.py [--force]
+
+hipcc cross-compiles without a GPU.  ``-ffp-contract=off`` keeps every float /
+double operation separately rounded, which the decode / NMS / warpAffine
+kernels rely on to reproduce the reference's op-by-op arithmetic.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(CSRC, "libfcp_hip.so")
+
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isfile(c) or c == "hipcc"):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _newer(a, deps):
+    if not os.path.isfile(a):
+        return False
+    t = os.path.getmtime(a)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    objs = []
+    procs = []
+    for src in sources():
+        obj = src[:-4] + ".o"
+        objs.append(obj)
+        if not force and _newer(obj, [src] + headers):
+            continue
+        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    failed = [s for s, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError(f"hipcc failed for: {failed}")
+    if force or procs or not _newer(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

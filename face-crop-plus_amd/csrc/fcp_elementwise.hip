@@ -1,0 +1,120 @@
+// HBM-bound glue kernels of the detector body: uint8 -> fp32 NHWC4 conversion
+// (mean subtraction / scaling fused) and the stem max-pool.  One 16-byte store
+// per lane, grid-stride, >= 2048 workgroups when the tensor is large enough.
+#include "fcp_common.h"
+#include "fcp_hip.h"
+
+#include <cstdarg>
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void fcp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* fcp_last_error(void) { return g_err; }
+extern "C" int fcp_abi_version(void) { return FCP_ABI_VERSION; }
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 4 pixels (12 bytes in, 64 bytes out) per thread iteration.
+__global__ void __launch_bounds__(256) u8_to_nhwc4_kernel(const uint8_t* __restrict__ in,
+                                                          float* __restrict__ out, long npix,
+                                                          float s0, float s1, float s2, float div,
+                                                          int do_div) {
+  const long nquad = npix >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + q * 12);
+    const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+    const uint8_t b[12] = {(uint8_t)w0, (uint8_t)(w0 >> 8), (uint8_t)(w0 >> 16), (uint8_t)(w0 >> 24),
+                           (uint8_t)w1, (uint8_t)(w1 >> 8), (uint8_t)(w1 >> 16), (uint8_t)(w1 >> 24),
+                           (uint8_t)w2, (uint8_t)(w2 >> 8), (uint8_t)(w2 >> 16), (uint8_t)(w2 >> 24)};
+    f32x4* dst = reinterpret_cast<f32x4*>(out + q * 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float r = (float)b[3 * k] - s0, g = (float)b[3 * k + 1] - s1, bl = (float)b[3 * k + 2] - s2;
+      if (do_div) { r = r / div; g = g / div; bl = bl / div; }
+      dst[k] = f32x4{r, g, bl, 0.f};
+    }
+  }
+  // tail (npix % 4 pixels), handled by the first threads of block 0
+  const long tail0 = nquad << 2;
+  if (blockIdx.x == 0 && threadIdx.x < (npix - tail0)) {
+    const long px = tail0 + threadIdx.x;
+    float r = (float)in[px * 3] - s0, g = (float)in[px * 3 + 1] - s1, bl = (float)in[px * 3 + 2] - s2;
+    if (do_div) { r = r / div; g = g / div; bl = bl / div; }
+    *reinterpret_cast<f32x4*>(out + px * 4) = f32x4{r, g, bl, 0.f};
+  }
+}
+
+__global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float* __restrict__ in,
+                                                           float* __restrict__ out, int n, int h,
+                                                           int w, int c4, int oh, int ow) {
+  const long total = (long)n * oh * ow * c4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const f32x4* in4 = reinterpret_cast<const f32x4*>(in);
+  f32x4* out4 = reinterpret_cast<f32x4*>(out);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cc = (int)(i % c4);
+    long t = i / c4;
+    const int x = (int)(t % ow);
+    t /= ow;
+    const int y = (int)(t % oh);
+    const int ni = (int)(t / oh);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = 2 * y - 1 + dy;
+      if ((unsigned)yy >= (unsigned)h) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = 2 * x - 1 + dx;
+        if ((unsigned)xx >= (unsigned)w) continue;
+        const f32x4 v = in4[(((long)ni * h + yy) * w + xx) * c4 + cc];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    out4[i] = m;
+  }
+}
+
+inline int grid_for(long work_items, int block) {
+  long g = (work_items + block - 1) / block;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int fcp_u8_to_nhwc4_f32(const uint8_t* in, float* out, int64_t npix,
+                                   const float* sub_host, float div, fcp_stream_t stream) {
+  FCP_REQUIRE(in && out && sub_host, "u8_to_nhwc4: null pointer");
+  FCP_REQUIRE(npix > 0, "u8_to_nhwc4: empty input");
+  FCP_REQUIRE(((uintptr_t)in & 3) == 0 && ((uintptr_t)out & 15) == 0, "u8_to_nhwc4: misaligned buffers");
+  const int do_div = div != 1.0f;
+  hipLaunchKernelGGL(u8_to_nhwc4_kernel, dim3(grid_for((npix + 3) / 4, 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, (long)npix, sub_host[0], sub_host[1], sub_host[2], div,
+                     do_div);
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int fcp_maxpool3x3s2_nhwc_f32(const float* in, float* out, int n, int h, int w, int c,
+                                         int out_h, int out_w, fcp_stream_t stream) {
+  FCP_REQUIRE(in && out, "maxpool: null pointer");
+  FCP_REQUIRE(c % 4 == 0, "maxpool: c must be a multiple of 4");
+  FCP_REQUIRE(out_h == (h + 2 - 3) / 2 + 1 && out_w == (w + 2 - 3) / 2 + 1, "maxpool: bad output size");
+  const long total = (long)n * out_h * out_w * (c / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     out, n, h, w, c / 4, out_h, out_w);
+  FCP_LAUNCH_OK();
+  return 0;
+}

@@ -1,0 +1,209 @@
+"""Host-side plumbing over the C ABI: NHWC activation views, filter packing
+(BatchNorm folding, OIHW -> OHWI, padding) and thin op wrappers.
+
+PyTorch is used only as the device allocator / stream provider; every compute
+call goes through ``libfcp_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+BN_EPS = 1e-5
+COUT_PAD = 128  # filters are zero-padded to a multiple of the largest N tile
+
+
+class Act:
+    """A channel-slice view of an NHWC fp32 device buffer.
+
+    ``buf`` has shape (n, h, w, ld); the view covers channels [c0, c0+c).  This
+    is how ``torch.cat`` along channels is realised without a copy: producers
+    write their slice, consumers read a wider slice.
+    """
+    __slots__ = ("buf", "c0", "c")
+
+    def __init__(self, buf: torch.Tensor, c0: int = 0, c: int | None = None):
+        assert buf.dim() == 4 and buf.dtype == torch.float32 and buf.is_contiguous()
+        self.buf, self.c0 = buf, c0
+        self.c = buf.shape[3] - c0 if c is None else c
+        assert 0 <= c0 and c0 + self.c <= buf.shape[3]
+
+    @staticmethod
+    def empty(n, h, w, c, device):
+        return Act(torch.empty((n, h, w, c), dtype=torch.float32, device=device))
+
+    @property
+    def n(self): return self.buf.shape[0]
+    @property
+    def h(self): return self.buf.shape[1]
+    @property
+    def w(self): return self.buf.shape[2]
+    @property
+    def ld(self): return self.buf.shape[3]
+
+    def slice(self, c0, c):
+        return Act(self.buf, self.c0 + c0, c)
+
+    def ptr(self):
+        return N.ptr(self.buf, 4 * self.c0)
+
+    def nchw(self) -> torch.Tensor:
+        """Copy out as an NCHW torch tensor (tests only)."""
+        return self.buf[..., self.c0:self.c0 + self.c].permute(0, 3, 1, 2).contiguous()
+
+
+@dataclass
+class PackedConv:
+    w: torch.Tensor          # packed filter on device
+    bias: torch.Tensor | None
+    cin: int
+    cout: int
+    kh: int
+    kw: int
+    stride: int
+    pad: int
+    cin4: bool
+    flops_per_pixel: int     # 2*cout*cin*kh*kw (algorithmic, unpadded)
+
+
+def fold_bn(weight: np.ndarray, bn: dict | None, bias: np.ndarray | None):
+    """conv -> BN(eval) folded into (weight, bias), fp32 like ATen's inference BN:
+    alpha = gamma / sqrt(var + eps); y = conv*alpha + (beta - mean*alpha)."""
+    w = np.asarray(weight, dtype=np.float32)
+    if bn is None:
+        return w, (None if bias is None else np.asarray(bias, np.float32))
+    f = np.float32
+    alpha = (bn["weight"].astype(f) / np.sqrt(bn["running_var"].astype(f) + f(BN_EPS))).astype(f)
+    beta = (bn["bias"].astype(f) - bn["running_mean"].astype(f) * alpha).astype(f)
+    if bias is not None:
+        beta = (beta + np.asarray(bias, f) * alpha).astype(f)
+    return (w * alpha[:, None, None, None]).astype(f), beta
+
+
+def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, device="cuda", cin_perm=None) -> PackedConv:
+    """weight: (cout,cin,kh,kw) numpy/torch; bn: dict with weight/bias/running_mean/running_var."""
+    if isinstance(weight, torch.Tensor):
+        weight = weight.detach().cpu().numpy()
+    if isinstance(bias, torch.Tensor):
+        bias = bias.detach().cpu().numpy()
+    if bn is not None:
+        bn = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in bn.items()}
+    w, b = fold_bn(weight, bn, bias)
+    if cin_perm is not None:
+        w = w[:, cin_perm]
+    cout, cin, kh, kw = w.shape
+    cout_pad = -(-cout // COUT_PAD) * COUT_PAD
+    cin4 = cin <= 4
+    if cin4:
+        assert kw <= 8
+        packed = np.zeros((cout_pad, kh, 8, 4), np.float32)
+        packed[:cout, :, :kw, :cin] = w.transpose(0, 2, 3, 1)
+    else:
+        assert cin % 32 == 0, f"cin={cin} must be a multiple of 32"
+        packed = np.zeros((cout_pad, kh, kw, cin), np.float32)
+        packed[:cout] = w.transpose(0, 2, 3, 1)
+    wd = torch.from_numpy(np.ascontiguousarray(packed)).to(device)
+    bd = None if b is None else torch.from_numpy(np.ascontiguousarray(b)).to(device)
+    return PackedConv(wd, bd, 4 if cin4 else cin, cout, kh, kw, stride, pad, cin4,
+                      2 * cout * cin * kh * kw)
+
+
+def bn_of(sd, prefix):
+    return {k: sd[f"{prefix}.{k}"] for k in ("weight", "bias", "running_mean", "running_var")}
+
+
+def _pick_tile_n(cout: int, m: int) -> int:
+    """Largest N tile that wastes no matrix work and still fills 256 CUs."""
+    if cout <= 32:
+        return 32
+    gm = -(-m // 128)
+    if cout % 128 == 0 and gm * (cout // 128) >= 512:
+        return 128
+    return 64
+
+
+class ConvStats:
+    """Algorithmic-FLOP accounting of conv launches (bench / roofline)."""
+    enabled = False
+    flops = 0
+    launches = 0
+    timing = None  # list of (start_event, end_event, flops) when per-launch timing is on
+
+    @classmethod
+    def reset(cls):
+        cls.flops, cls.launches = 0, 0
+        if cls.timing is not None:
+            cls.timing = []
+
+
+def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1.0,
+         alpha: float = 1.0, res1: Act | None = None, res1_pre: bool = True,
+         res2: Act | None = None, alpha2: float = 1.0, in_up2: bool = False,
+         tile_n: int | None = None) -> Act:
+    """Launch one fused convolution.  ``act_slope``: 1 = identity, 0 = ReLU."""
+    assert x.c == pc.cin, f"conv expects {pc.cin} input channels, got {x.c}"
+    in_h, in_w = (x.h * 2, x.w * 2) if in_up2 else (x.h, x.w)
+    oh = (in_h + 2 * pc.pad - pc.kh) // pc.stride + 1
+    ow = (in_w + 2 * pc.pad - pc.kw) // pc.stride + 1
+    if out is None:
+        out = Act.empty(x.n, oh, ow, pc.cout, x.buf.device)
+    assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, pc.cout), "conv: bad output view"
+    m = x.n * oh * ow
+    d = N.ConvDesc()
+    d.in_, d.w, d.out = x.ptr(), N.ptr(pc.w), out.ptr()
+    d.bias = N.ptr(pc.bias)
+    d.res1 = res1.ptr() if res1 is not None else None
+    d.res2 = res2.ptr() if res2 is not None else None
+    d.n, d.in_h, d.in_w = x.n, in_h, in_w
+    d.cin, d.in_ld, d.in_up2 = pc.cin, x.ld, int(in_up2)
+    d.cout, d.kh, d.kw, d.stride, d.pad = pc.cout, pc.kh, pc.kw, pc.stride, pc.pad
+    d.out_h, d.out_w, d.out_ld = oh, ow, out.ld
+    d.tile_n = tile_n or _pick_tile_n(pc.cout, m)
+    d.cin4 = int(pc.cin4)
+    d.act_slope, d.alpha, d.alpha2 = act_slope, alpha, alpha2
+    d.res1_pre = int(res1_pre)
+    if res1 is not None:
+        assert res1.c == pc.cout and res1.n == x.n
+        d.res1_ld, d.res1_h, d.res1_w = res1.ld, res1.h, res1.w
+    if res2 is not None:
+        assert (res2.n, res2.h, res2.w, res2.c) == (x.n, oh, ow, pc.cout)
+        d.res2_ld = res2.ld
+    timing = ConvStats.timing
+    if timing is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
+    if timing is not None:
+        e1.record()
+        timing.append((e0, e1, pc.flops_per_pixel * m))
+    if ConvStats.enabled:
+        ConvStats.flops += pc.flops_per_pixel * m
+        ConvStats.launches += 1
+    return out
+
+
+def u8_to_nhwc4(images_u8: torch.Tensor, sub=(0.0, 0.0, 0.0), div: float = 1.0) -> Act:
+    """(n,h,w,3) uint8 device tensor -> fp32 NHWC4 activation ((x - sub) / div)."""
+    assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[3] == 3
+    assert images_u8.is_contiguous()
+    n, h, w, _ = images_u8.shape
+    out = Act.empty(n, h, w, 4, images_u8.device)
+    sub_arr = (C.c_float * 3)(*[float(s) for s in sub])
+    N.check(N.lib().fcp_u8_to_nhwc4_f32(N.ptr(images_u8), out.ptr(), n * h * w, sub_arr, float(div),
+                                        N.stream_ptr()), "fcp_u8_to_nhwc4_f32")
+    return out
+
+
+def maxpool3x3s2(x: Act) -> Act:
+    assert x.c0 == 0 and x.c == x.ld
+    oh, ow = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1
+    out = Act.empty(x.n, oh, ow, x.c, x.buf.device)
+    N.check(N.lib().fcp_maxpool3x3s2_nhwc_f32(x.ptr(), out.ptr(), x.n, x.h, x.w, x.c, oh, ow,
+                                              N.stream_ptr()), "fcp_maxpool3x3s2_nhwc_f32")
+    return out

@@ -1,0 +1,227 @@
+"""State-dict specs, deterministic weight generator and ``.pth`` loading.
+
+The three networks keep the reference's state_dict key names so that the real
+checkpoints (``retinaface_detector.pth`` / ``bsrgan_x4_enhancer.pth`` /
+``bise_parser.pth``, reference ``models/_layers.py:12-35``,
+``retinaface.py:52``, ``rrdb.py:35``, ``bise.py:120``) load unchanged when a
+user supplies them.  There is no network here, so tests / bench use
+:func:`generate_state_dict`: seeded, Kaiming-scaled conv weights and
+*non-trivial* BatchNorm statistics (default ``mean=0,var=1`` would hide
+folding bugs).
+"""
+from __future__ import annotations
+
+import os
+import numpy as np
+
+# kind tags
+CONV_W, CONV_B, BN_W, BN_B, BN_RM, BN_RV, BN_NBT = range(7)
+
+WEIGHTS_FILENAMES = {
+    "retinaface": "retinaface_detector.pth",
+    "rrdb": "bsrgan_x4_enhancer.pth",
+    "bisenet": "bise_parser.pth",
+}
+
+
+def _conv(spec, name, cout, cin, k, bias=False):
+    spec.append((name + ".weight", (cout, cin, k, k), CONV_W))
+    if bias:
+        spec.append((name + ".bias", (cout,), CONV_B))
+
+
+def _bn(spec, name, c):
+    spec.append((name + ".weight", (c,), BN_W))
+    spec.append((name + ".bias", (c,), BN_B))
+    spec.append((name + ".running_mean", (c,), BN_RM))
+    spec.append((name + ".running_var", (c,), BN_RV))
+    spec.append((name + ".num_batches_tracked", (), BN_NBT))
+
+
+def retinaface_spec():
+    """Keys/shapes of ``RetinaFace`` (reference retinaface.py:93-110; torchvision
+    ResNet-50 v1.5 body through ``IntermediateLayerGetter``, so no avgpool/fc)."""
+    s = []
+    _conv(s, "body.conv1", 64, 3, 7)
+    _bn(s, "body.bn1", 64)
+    inplanes = 64
+    for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), (3, 4, 6, 3)), 1):
+        for b in range(blocks):
+            p = f"body.layer{li}.{b}"
+            _conv(s, p + ".conv1", planes, inplanes, 1)
+            _bn(s, p + ".bn1", planes)
+            _conv(s, p + ".conv2", planes, planes, 3)
+            _bn(s, p + ".bn2", planes)
+            _conv(s, p + ".conv3", planes * 4, planes, 1)
+            _bn(s, p + ".bn3", planes * 4)
+            if b == 0:
+                _conv(s, p + ".downsample.0", planes * 4, inplanes, 1)
+                _bn(s, p + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+    for i, cin in enumerate((512, 1024, 2048), 1):
+        _conv(s, f"fpn.output{i}.0", 256, cin, 1)
+        _bn(s, f"fpn.output{i}.1", 256)
+    for i in (1, 2):
+        _conv(s, f"fpn.merge{i}.0", 256, 256, 3)
+        _bn(s, f"fpn.merge{i}.1", 256)
+    for k in (1, 2, 3):
+        for nm, co, ci in (("conv3X3", 128, 256), ("conv5X5_1", 64, 256),
+                           ("conv5X5_2", 64, 64), ("conv7X7_2", 64, 64),
+                           ("conv7x7_3", 64, 64)):
+            _conv(s, f"ssh{k}.{nm}.0", co, ci, 3)
+            _bn(s, f"ssh{k}.{nm}.1", co)
+    for head, nout in (("ClassHead", 2), ("BboxHead", 4), ("LandmarkHead", 10)):
+        for i in range(3):
+            _conv(s, f"{head}.{i}.conv1x1", 2 * nout, 256, 1, bias=True)
+    return s
+
+
+def rrdb_spec():
+    """Keys/shapes of ``RRDBNet`` (reference rrdb.py:53-62, _layers.py:168-200)."""
+    s = []
+    _conv(s, "conv_first", 64, 3, 3, bias=True)
+    for t in range(23):
+        for r in (1, 2, 3):
+            p = f"RRDB_trunk.{t}.RDB{r}"
+            for c in range(1, 5):
+                _conv(s, f"{p}.conv{c}", 32, 64 + 32 * (c - 1), 3, bias=True)
+            _conv(s, f"{p}.conv5", 64, 192, 3, bias=True)
+    for nm in ("trunk_conv", "upconv1", "upconv2", "HRconv"):
+        _conv(s, nm, 64, 64, 3, bias=True)
+    _conv(s, "conv_last", 3, 64, 3, bias=True)
+    return s
+
+
+def bisenet_spec():
+    """Keys/shapes of ``BiSeNet`` (reference bise.py:191-193, _layers.py:206-368)."""
+    s = []
+    _conv(s, "cp.resnet.conv1", 64, 3, 7)
+    _bn(s, "cp.resnet.bn1", 64)
+    cin = 64
+    for li, cout in enumerate((64, 128, 256, 512), 1):
+        for b in range(2):
+            p = f"cp.resnet.layer{li}.{b}"
+            _conv(s, p + ".conv1", cout, cin, 3)
+            _bn(s, p + ".bn1", cout)
+            _conv(s, p + ".conv2", cout, cout, 3)
+            _bn(s, p + ".bn2", cout)
+            if b == 0 and (cin != cout or li != 1):
+                _conv(s, p + ".downsample.0", cout, cin, 1)
+                _bn(s, p + ".downsample.1", cout)
+            cin = cout
+    for nm, ci in (("arm16", 256), ("arm32", 512)):
+        _conv(s, f"cp.{nm}.conv.conv", 128, ci, 3)
+        _bn(s, f"cp.{nm}.conv.bn", 128)
+        _conv(s, f"cp.{nm}.conv_atten", 128, 128, 1)
+        _bn(s, f"cp.{nm}.bn_atten", 128)
+    for nm in ("conv_head32", "conv_head16"):
+        _conv(s, f"cp.{nm}.conv", 128, 128, 3)
+        _bn(s, f"cp.{nm}.bn", 128)
+    _conv(s, "cp.conv_avg.conv", 128, 512, 1)
+    _bn(s, "cp.conv_avg.bn", 128)
+    _conv(s, "ffm.convblk.conv", 256, 256, 1)
+    _bn(s, "ffm.convblk.bn", 256)
+    _conv(s, "ffm.conv1", 64, 256, 1)
+    _conv(s, "ffm.conv2", 256, 64, 1)
+    _conv(s, "conv_out.conv.conv", 256, 256, 3)
+    _bn(s, "conv_out.conv.bn", 256)
+    _conv(s, "conv_out.conv_out", 19, 256, 1)
+    return s
+
+
+SPECS = {"retinaface": retinaface_spec, "rrdb": rrdb_spec, "bisenet": bisenet_spec}
+
+# Offset added to the "face" logit bias of the generated RetinaFace ClassHead so
+# that a realistic *minority* of the priors clears det_threshold=0.6 on i.i.d.
+# noise images (calibrated with tools/calibrate_cls_bias.py).
+GENERATED_CLS_BIAS_SHIFT = 0.1
+
+
+def generate_state_dict(model: str, seed: int = 0, as_torch: bool = True):
+    """Deterministic random-init state dict with reference key names.
+
+    conv weights ~ N(0, gain/fan_in); BN gamma in U(0.6,1.2), beta N(0,0.1),
+    running_mean N(0,0.1), running_var U(0.5,1.5).  Residual-branch tails are
+    damped so activations stay O(1) through 50+ layers in fp32.
+    """
+    rng = np.random.default_rng(np.random.PCG64(0x5EED0000 + 7919 * seed
+                                                + {"retinaface": 1, "rrdb": 2, "bisenet": 3}[model]))
+    out = {}
+    for name, shape, kind in SPECS[model]():
+        if kind == CONV_W:
+            fan_in = shape[1] * shape[2] * shape[3]
+            gain = 2.0
+            if model == "rrdb":
+                # dense blocks: LeakyReLU(0.2) and x5*0.2 residual scaling
+                gain = 1.0
+            if name.endswith("conv1x1.weight"):
+                gain = 0.01   # head inputs have std ~10: keep regressions O(1)
+            if "conv_out.conv_out" in name or name.startswith("conv_last"):
+                gain = 1.0
+            a = rng.standard_normal(shape, dtype=np.float32) * np.float32(np.sqrt(gain / fan_in))
+        elif kind == CONV_B:
+            a = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.05)
+            if model == "retinaface" and name.startswith("ClassHead"):
+                # channels are (anchor0: bg, face, anchor1: bg, face)
+                a = a.copy()
+                a[1::2] += np.float32(GENERATED_CLS_BIAS_SHIFT)
+        elif kind == BN_W:
+            lo, hi = (0.6, 1.2)
+            if name.endswith("bn3.weight") or (model == "bisenet" and name.endswith("bn2.weight")):
+                lo, hi = (0.25, 0.5)     # damp the residual branch
+            a = rng.uniform(lo, hi, shape).astype(np.float32)
+        elif kind == BN_B:
+            a = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+        elif kind == BN_RM:
+            a = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+        elif kind == BN_RV:
+            a = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+            if model == "retinaface" and name == "body.bn1.running_var":
+                # stem sees raw 0..255 pixels minus the channel means: conv1's
+                # output variance is ~2*E[x^2] ~ 1.1e4 — normalise it like a
+                # trained BN would so activations are O(1) from layer1 on
+                a = a * np.float32(11200.0)
+        else:
+            a = np.array(1, dtype=np.int64)
+        out[name] = a
+    if as_torch:
+        import torch
+        out = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in out.items()}
+    return out
+
+
+def find_checkpoint(model: str):
+    """Locate a user-supplied real checkpoint (never downloads; reference
+    ``LoadMixin.get_weights`` uses torch.hub, _layers.py:27-35)."""
+    fn = WEIGHTS_FILENAMES[model]
+    cands = []
+    if os.environ.get("FCP_WEIGHTS_DIR"):
+        cands.append(os.path.join(os.environ["FCP_WEIGHTS_DIR"], fn))
+    cands.append(os.path.join(os.path.expanduser("~/.cache/torch/hub/checkpoints"), fn))
+    for c in cands:
+        if os.path.isfile(c):
+            return c
+    return None
+
+
+def load_state_dict(model: str, source=None, seed: int = 0):
+    """``source``: None (checkpoint if found, else generated), a path, a dict, or
+    the string ``"generated"``."""
+    import torch
+    if isinstance(source, dict):
+        sd = source
+    elif source == "generated":
+        sd = generate_state_dict(model, seed)
+    else:
+        path = source if isinstance(source, str) else find_checkpoint(model)
+        if path is None:
+            sd = generate_state_dict(model, seed)
+        else:
+            sd = torch.load(path, map_location="cpu")
+    want = {n: tuple(s) for n, s, _ in SPECS[model]()}
+    for k, shp in want.items():
+        if k not in sd:
+            raise KeyError(f"{model}: missing key {k}")
+        if tuple(sd[k].shape) != shp:
+            raise ValueError(f"{model}: {k} has shape {tuple(sd[k].shape)}, expected {shp}")
+    return sd

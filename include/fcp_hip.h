@@ -1,0 +1,171 @@
+/*
+ * fcp_hip.h — C ABI of the MI355X (gfx950) hot path of face-crop-plus.
+ *
+ * The reference (mantasu/face-crop-plus) is pure Python: it has no FFI layer.
+ * Its seam for this path is the object protocol `Cropper` uses on its three
+ * models plus `crop_align`.  This header is the native side of
+ * that seam: stateless entry points, plain pointers and sizes, every pointer a
+ * *device* pointer unless the name ends in `_host`.  All work is enqueued on
+ * the caller's HIP stream (`stream` is a hipStream_t passed as void*); nothing
+ * synchronises, nothing allocates, nothing keeps global state except the
+ * thread-local last-error string.  Every function returns 0 on success and a
+ * negative code on misuse (message via fcp_last_error()).
+ *
+ * Each entry point cites the reference code it replaces (paths relative to
+ * src/face_crop_plus/ of the reference tree).
+ */
+#ifndef FCP_HIP_H
+#define FCP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCP_ABI_VERSION 1
+
+typedef void* fcp_stream_t; /* hipStream_t */
+
+int fcp_abi_version(void);
+const char* fcp_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Convolution engine (NHWC fp32 implicit GEMM on v_mfma_f32_32x32x2_f32).
+ * Replaces every nn.Conv2d(+BatchNorm eval)(+ReLU/LeakyReLU)(+residual) the
+ * three networks dispatch to ATen: models/_layers.py:64-162 (SSH/FPN/Head),
+ * :168-200 (RRDB blocks), :206-368 (BiSeNet blocks), torchvision ResNet-50
+ * body (models/retinaface.py:93-99).
+ *
+ * Tensor layout: activations are NHWC fp32.  `in`/`out`/`res*` may point into
+ * a wider buffer: `*_ld` is the channel stride (floats per pixel) of that
+ * buffer and the pointer is already offset to the first channel used.  This
+ * is how torch.cat (SSH, dense blocks, FFM) is realised with no copy.
+ *
+ * Filter layout (produced by the host packer, see engine.py pack_conv):
+ *   normal mode : [cout_pad][kh][kw][cin]            cin % 32 == 0
+ *   cin4 mode   : [cout_pad][kh][8][4]               cin <= 4, kw <= 8
+ * cout_pad = cout rounded up to the N tile (32/64/128) chosen by `tile_n`;
+ * the padding rows are zero.  BatchNorm (eval) is folded into w and bias.
+ *
+ * Epilogue (fp32, in this order):
+ *   v = acc + bias[co]
+ *   if (res1 && res1_pre)  v += res1[...]
+ *   v = v >= 0 ? v : v * act_slope        (act_slope = 1 -> identity, 0 -> ReLU)
+ *   v = v * alpha
+ *   if (res1 && !res1_pre) v += res1[...]
+ *   if (res2)              v = v * alpha2 + res2[...]
+ * res1 may have a different spatial size (res1_h,res1_w): it is then read with
+ * PyTorch's nearest rule  src = min(floor(dst * (float)src_size/dst_size), src_size-1)
+ * (FPN top-down add, _layers.py:137-143).  res2 always has the output's size.
+ * ------------------------------------------------------------------------ */
+typedef struct fcp_conv_desc {
+  const float* in;    /* (n, in_h_phys, in_w_phys, in_ld) */
+  const float* w;     /* packed filter */
+  const float* bias;  /* [cout] or NULL */
+  float* out;         /* (n, out_h, out_w, out_ld) */
+  const float* res1;  /* or NULL */
+  const float* res2;  /* or NULL */
+  int32_t n, in_h, in_w; /* logical input size (after the optional x2 upsample) */
+  int32_t cin, in_ld;
+  int32_t in_up2;     /* 1: physical input is (in_h/2, in_w/2), read at (h>>1, w>>1)
+                         = F.interpolate(scale_factor=2 / exact-2x size, "nearest")
+                         (rrdb.py:78-79, _layers.py:338,:343) */
+  int32_t cout, kh, kw, stride, pad;
+  int32_t out_h, out_w, out_ld;
+  int32_t tile_n;     /* 32, 64 or 128: N tile the filter was packed for */
+  int32_t cin4;       /* 1: cin4 mode */
+  float act_slope, alpha, alpha2;
+  int32_t res1_pre, res1_ld, res1_h, res1_w, res2_ld;
+} fcp_conv_desc;
+
+int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);
+
+/* uint8 NHWC RGB (n,h,w,3) -> fp32 NHWC4 (n,h,w,4): out[c] = (in[c]-sub[c])/div, out[3]=0.
+ * Replaces utils.py:222-224 (as_tensor) fused with retinaface.py:450-451 (mean
+ * subtraction; the BGR swap is folded into the stem filter's channel order) or
+ * with rrdb.py:142 (`.div(255)`).  sub_host: 3 floats on the host. */
+int fcp_u8_to_nhwc4_f32(const uint8_t* in, float* out, int64_t npix,
+                        const float* sub_host, float div, fcp_stream_t stream);
+
+/* MaxPool2d(kernel 3, stride 2, pad 1) on NHWC fp32 (torchvision ResNet stem,
+ * _layers.py:247).  c % 4 == 0. */
+int fcp_maxpool3x3s2_nhwc_f32(const float* in, float* out, int n, int h, int w, int c,
+                              int out_h, int out_w, fcp_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * RetinaFace post-processing.
+ * ------------------------------------------------------------------------ */
+
+/* Fused softmax + analytic PriorBox + decode + strict threshold + ordered
+ * compaction.  Replaces retinaface.py:144 (softmax), _layers.py:41-62
+ * (PriorBox), retinaface.py:169-178/:204-210/:455-461 (decode + scale) and
+ * retinaface.py:264-267 (score > vis mask + gather).
+ *
+ * head[l]: fused head conv output of pyramid level l (stride 8/16/32), NHWC
+ * with 32 channels per pixel: [cls a0(bg,face) a1(bg,face) | box a0(4) a1(4) |
+ * landm a0(10) a1(10)]; level sizes are ceil(h/stride) x ceil(w/stride).
+ * Outputs (per image, capacity P = total priors, candidates in ascending
+ * prior order): cand_score (n,P), cand_box (n,P,4), cand_ldm (n,P,10),
+ * cand_prior (n,P) int32, cand_count (n) int32.
+ * dense_* are optional (NULL to skip): full (n,P) / (n,P,4) / (n,P,10). */
+int fcp_retina_decode(const float* head0, const float* head1, const float* head2,
+                      int n, int img_h, int img_w, float vis_threshold,
+                      float var0, float var1,
+                      float* cand_score, float* cand_box, float* cand_ldm,
+                      int32_t* cand_prior, int32_t* cand_count,
+                      float* dense_score, float* dense_box, float* dense_ldm,
+                      fcp_stream_t stream);
+
+/* Per-image sort (score desc, candidate position asc) + greedy NMS with the
+ * reference's +1-pixel IoU and `ovr <= nms_threshold` survival rule
+ * (retinaface.py:270-298), followed by take_by_strategy (retinaface.py:363-408).
+ * strategy: 0 = all, 1 = best, 2 = largest.
+ * workspace: n * cap * 8 bytes (sort keys), cap = candidate capacity (stride of
+ * the cand_* arrays).  Outputs: keep_pos (n,cap) int32 = candidate positions of
+ * the kept boxes in keep order, keep_count (n); sel_pos (n,cap) / sel_count (n)
+ * = the positions take_by_strategy selects (for "all" identical to keep). */
+int fcp_retina_nms_select(const float* cand_score, const float* cand_box,
+                          const int32_t* cand_count, int n, int cap,
+                          float nms_threshold, int strategy, void* workspace,
+                          int32_t* keep_pos, int32_t* keep_count,
+                          int32_t* sel_pos, int32_t* sel_count, fcp_stream_t stream);
+
+/* Gather the selected faces into dense, image-major arrays (the return value
+ * of RetinaFace.predict, retinaface.py:465-470, minus the D2H copy) and apply
+ * the landmark un-padding of cropper.py:822 (paddings (n,4) int32 t,b,l,r or NULL).
+ * face_offset: (n+1) int32 exclusive prefix of sel_count (written here).
+ * out_ldm (max_faces,5,2) f32, out_img (max_faces) int32. */
+int fcp_retina_gather_faces(const float* cand_ldm, const int32_t* sel_pos,
+                            const int32_t* sel_count, int n, int cap,
+                            const int32_t* paddings, int max_faces,
+                            int32_t* face_offset, float* out_ldm, int32_t* out_img,
+                            fcp_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Align + crop.
+ * ------------------------------------------------------------------------ */
+
+/* Least-squares 2x3 transform from 5 (or k) source points to target points:
+ * similarity (4 dof) = cv2.estimateAffinePartial2D, full affine (6 dof) =
+ * cv2.estimateAffine2D, both with ransacReprojThreshold=inf (cropper.py:515-527).
+ * src (f,k,2) f32, dst (k,2) f32 -> mat (f,6) f64 row-major, ok (f) int32
+ * (0 = degenerate / non-finite: the reference drops that face, cropper.py:529-531). */
+int fcp_estimate_transform(const float* src, const float* dst, int f, int k,
+                           int allow_skew, double* mat, int32_t* ok, fcp_stream_t stream);
+
+/* cv2.warpAffine(image, M, dsize, flags=INTER_LINEAR, borderMode) on the
+ * un-padded slice of each face's batch image (cropper.py:533-547): OpenCV's
+ * fixed-point algorithm (AB_BITS=10, INTER_BITS=5, 15-bit weights).
+ * images (n,h,w,3) u8; img_idx (f) int32; mat (f,6) f64 forward transforms;
+ * paddings (n,4) int32 (t,b,l,r) or NULL; border: 0 constant(0), 1 replicate,
+ * 2 reflect, 3 wrap, 4 reflect_101 (= cv2.BORDER_*); out (f,out_h,out_w,3) u8. */
+int fcp_warp_affine_u8(const uint8_t* images, int n, int h, int w,
+                       const int32_t* img_idx, const double* mat, const int32_t* ok,
+                       const int32_t* paddings, int f, int out_h, int out_w, int border,
+                       uint8_t* out, fcp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCP_HIP_H */

@@ -1,0 +1,142 @@
+"""HIP conv engine vs a plain PyTorch fp32 (CPU) reference of the same op."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(x, device):  # NCHW cpu -> NHWC device
+    return x.permute(0, 2, 3, 1).contiguous().to(device)
+
+
+def _tol(ref):
+    return 2e-5 * float(ref.abs().max()) + 1e-6
+
+
+CASES = [
+    # n, h, w, cin, cout, k, stride, pad
+    (2, 17, 23, 64, 64, 1, 1, 0),
+    (1, 40, 40, 64, 256, 1, 1, 0),
+    (2, 20, 20, 256, 64, 3, 1, 1),
+    (1, 33, 29, 128, 128, 3, 2, 1),
+    (2, 16, 16, 256, 512, 1, 2, 0),
+    (1, 12, 12, 512, 32, 1, 1, 0),
+    (1, 24, 24, 96, 32, 3, 1, 1),
+    (1, 24, 24, 192, 64, 3, 1, 1),
+    (1, 16, 16, 256, 19, 1, 1, 0),
+    (1, 32, 32, 64, 3, 3, 1, 1),
+    (3, 10, 10, 256, 192, 3, 1, 1),
+    (1, 64, 64, 256, 256, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_plain(case, device):
+    from face_crop_plus_amd import engine as E
+    n, h, w, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, stride, pad)
+    pc = E.pack_conv(wt, b, None, stride, pad, device)
+    for tile_n in ([32] if cout <= 32 else [64, 128]):
+        out = E.conv(pc, E.Act(_nhwc(x, device)), tile_n=tile_n).nchw().cpu()
+        assert out.shape == ref.shape
+        err = (out - ref).abs().max().item()
+        assert err <= _tol(ref), f"tile_n={tile_n} err={err}"
+
+
+def test_conv_bn_relu_residual_pre(device):
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 64, 19, 21, generator=g)
+    wt = torch.randn(256, 64, 1, 1, generator=g) / 8
+    bn = dict(weight=torch.rand(256, generator=g) + 0.5, bias=torch.randn(256, generator=g),
+              running_mean=torch.randn(256, generator=g), running_var=torch.rand(256, generator=g) + 0.5)
+    res = torch.randn(2, 256, 19, 21, generator=g)
+    ref = F.relu(F.batch_norm(F.conv2d(x, wt), bn["running_mean"], bn["running_var"], bn["weight"],
+                              bn["bias"], False, 0.0, 1e-5) + res)
+    pc = E.pack_conv(wt, None, bn, 1, 0, device)
+    out = E.conv(pc, E.Act(_nhwc(x, device)), act_slope=0.0, res1=E.Act(_nhwc(res, device)), res1_pre=True)
+    assert (out.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+
+
+def test_conv_residual_post_nearest(device):
+    """FPN: lrelu(bn(conv1x1(x))) + nearest_up(res) with a non-2x size ratio."""
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 512, 13, 15, generator=g)
+    wt = torch.randn(256, 512, 1, 1, generator=g) / 22
+    res = torch.randn(1, 256, 7, 8, generator=g)
+    ref = F.leaky_relu(F.conv2d(x, wt), 0.0) + F.interpolate(res, size=(13, 15), mode="nearest")
+    pc = E.pack_conv(wt, None, None, 1, 0, device)
+    out = E.conv(pc, E.Act(_nhwc(x, device)), act_slope=0.0, res1=E.Act(_nhwc(res, device)), res1_pre=False)
+    assert (out.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+
+
+def test_conv_rrdb_epilogue_and_slices(device):
+    """Dense-block style: read a channel slice of a wide buffer, write another
+    slice, LeakyReLU(0.2); then conv5-style ((acc+b)*0.2 + x)*0.2 + y."""
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(3)
+    n, h, w = 1, 18, 22
+    feat = torch.randn(n, 192, h, w, generator=g)
+    w2 = torch.randn(32, 96, 3, 3, generator=g) / 30
+    b2 = torch.randn(32, generator=g)
+    buf = E.Act(_nhwc(feat, device))
+    ref2 = F.leaky_relu(F.conv2d(feat[:, :96], w2, b2, 1, 1), 0.2)
+    pc2 = E.pack_conv(w2, b2, None, 1, 1, device)
+    E.conv(pc2, buf.slice(0, 96), buf.slice(96, 32), act_slope=0.2)
+    got = buf.slice(96, 32).nchw().cpu()
+    assert (got - ref2).abs().max().item() <= _tol(ref2)
+    feat2 = buf.nchw().cpu()
+    w5 = torch.randn(64, 192, 3, 3, generator=g) / 40
+    b5 = torch.randn(64, generator=g)
+    xin = feat2[:, :64]
+    y = torch.randn(n, 64, h, w, generator=g)
+    ref5 = (F.conv2d(feat2, w5, b5, 1, 1) * 0.2 + xin) * 0.2 + y
+    pc5 = E.pack_conv(w5, b5, None, 1, 1, device)
+    out = E.conv(pc5, buf, alpha=0.2, res1=buf.slice(0, 64), res1_pre=False, res2=E.Act(_nhwc(y, device)),
+                 alpha2=0.2)
+    assert (out.nchw().cpu() - ref5).abs().max().item() <= _tol(ref5)
+
+
+def test_conv_upsampled_input(device):
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 64, 9, 11, generator=g)
+    wt = torch.randn(64, 64, 3, 3, generator=g) / 24
+    b = torch.randn(64, generator=g)
+    ref = F.leaky_relu(F.conv2d(F.interpolate(x, scale_factor=2), wt, b, 1, 1), 0.2)
+    pc = E.pack_conv(wt, b, None, 1, 1, device)
+    out = E.conv(pc, E.Act(_nhwc(x, device)), act_slope=0.2, in_up2=True)
+    assert (out.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+
+
+@pytest.mark.parametrize("k,stride,pad", [(7, 2, 3), (3, 1, 1)])
+def test_conv_stem_cin4(k, stride, pad, device):
+    """u8 image -> NHWC4 (mean subtraction fused) -> cin4-mode stem conv."""
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (2, 37, 45, 3), generator=g, dtype=torch.uint8)
+    wt = torch.randn(64, 3, k, k, generator=g) / (3 * k * k) ** 0.5
+    mean = torch.tensor([104.0, 117.0, 123.0])
+    x = img.permute(0, 3, 1, 2).float()
+    ref = F.relu(F.conv2d(x[:, [2, 1, 0]] - mean.view(3, 1, 1), wt, None, stride, pad))
+    # kernel keeps RGB order: permute the filter's input channels and the means instead
+    a = E.u8_to_nhwc4(img.to(device), sub=(123.0, 117.0, 104.0))
+    pc = E.pack_conv(wt, None, None, stride, pad, device, cin_perm=[2, 1, 0])
+    out = E.conv(pc, a, act_slope=0.0)
+    assert (out.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+
+
+def test_maxpool(device):
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 64, 37, 41, generator=g)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    out = E.maxpool3x3s2(E.Act(_nhwc(x, device))).nchw().cpu()
+    assert torch.equal(out, ref)
