@@ -39,6 +39,7 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 SIGNATURES = {
     "fcp_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P],
     "fcp_u8_to_nhwc4_f32": [_P, _P, _L, C.POINTER(C.c_float), _F, _P],
+    "fcp_f32nchw_to_nhwc4_f32": [_P, _P, _I, _I, _I, C.POINTER(C.c_float), _F, _P],
     "fcp_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "fcp_retina_decode": [_P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "fcp_retina_nms_select": [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
@@ -46,7 +47,7 @@ SIGNATURES = {
     "fcp_estimate_transform": [_P, _P, _I, _I, _I, _P, _P, _P],
     "fcp_warp_affine_u8": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
 }
-EXPORTS = ["fcp_abi_version", "fcp_last_error"] + list(SIGNATURES)
+EXPORTS = ["fcp_abi_version", "fcp_last_error", "fcp_retina_nms_workspace_bytes"] + list(SIGNATURES)
 
 
 def lib():
@@ -63,6 +64,8 @@ def lib():
     l.fcp_last_error.restype = C.c_char_p
     if l.fcp_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libfcp_hip.so ABI {l.fcp_abi_version()} != expected {ABI_VERSION}; rebuild")
+    l.fcp_retina_nms_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    l.fcp_retina_nms_workspace_bytes.restype = C.c_int64
     for name, args in SIGNATURES.items():
         fn = getattr(l, name)
         fn.argtypes = args

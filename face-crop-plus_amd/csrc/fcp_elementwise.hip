@@ -54,6 +54,23 @@ __global__ void __launch_bounds__(256) u8_to_nhwc4_kernel(const uint8_t* __restr
   }
 }
 
+// fp32 NCHW (3 planes) -> fp32 NHWC4, same affine as above (reference-API entry:
+// RetinaFace.predict / RRDBNet.predict receive float NCHW tensors).
+__global__ void __launch_bounds__(256) f32nchw_to_nhwc4_kernel(const float* __restrict__ in,
+                                                               float* __restrict__ out, int n, long hw,
+                                                               float s0, float s1, float s2, float div,
+                                                               int do_div) {
+  const long total = (long)n * hw;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long ni = i / hw, p = i - ni * hw;
+    const float* src = in + ni * 3 * hw + p;
+    float r = src[0] - s0, g = src[hw] - s1, b = src[2 * hw] - s2;
+    if (do_div) { r = r / div; g = g / div; b = b / div; }
+    *reinterpret_cast<f32x4*>(out + i * 4) = f32x4{r, g, b, 0.f};
+  }
+}
+
 __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float* __restrict__ in,
                                                            float* __restrict__ out, int n, int h,
                                                            int w, int c4, int oh, int ow) {
@@ -103,6 +120,18 @@ extern "C" int fcp_u8_to_nhwc4_f32(const uint8_t* in, float* out, int64_t npix,
   hipLaunchKernelGGL(u8_to_nhwc4_kernel, dim3(grid_for((npix + 3) / 4, 256)), dim3(256), 0,
                      (hipStream_t)stream, in, out, (long)npix, sub_host[0], sub_host[1], sub_host[2], div,
                      do_div);
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int fcp_f32nchw_to_nhwc4_f32(const float* in, float* out, int n, int h, int w,
+                                        const float* sub_host, float div, fcp_stream_t stream) {
+  FCP_REQUIRE(in && out && sub_host, "f32nchw_to_nhwc4: null pointer");
+  FCP_REQUIRE(n > 0 && h > 0 && w > 0, "f32nchw_to_nhwc4: empty input");
+  FCP_REQUIRE(((uintptr_t)out & 15) == 0, "f32nchw_to_nhwc4: misaligned output");
+  const long hw = (long)h * w;
+  hipLaunchKernelGGL(f32nchw_to_nhwc4_kernel, dim3(grid_for(n * hw, 256)), dim3(256), 0, (hipStream_t)stream,
+                     in, out, n, hw, sub_host[0], sub_host[1], sub_host[2], div, (int)(div != 1.0f));
   FCP_LAUNCH_OK();
   return 0;
 }

@@ -1,0 +1,418 @@
+// RetinaFace post-processing on gfx950: fused softmax + analytic priors +
+// decode + strict threshold + order-preserving compaction (wave ballot + LDS
+// scan), then per-image bitonic sort + tiled greedy NMS + strategy select.
+//
+// All float arithmetic is written op-by-op in the reference's order and the
+// file is built with -ffp-contract=off, so given identical inputs the NMS /
+// selection *indices* are bit-exact against the reference (and the oracle).
+#include "fcp_common.h"
+#include "fcp_hip.h"
+
+namespace {
+
+constexpr int DEC_THREADS = 1024;
+constexpr int NMS_THREADS = 1024;
+constexpr int SORT_LDS_KEYS = 8192;  // 64 KiB of 8-byte keys
+
+struct Levels {
+  int h[3], w[3], start[4];
+};
+
+__device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------
+// decode: one workgroup per image walks its priors in ascending order.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(DEC_THREADS) retina_decode_kernel(
+    const float* __restrict__ head0, const float* __restrict__ head1, const float* __restrict__ head2,
+    Levels lv, int img_h, int img_w, float thr, float v0, float v1, float* __restrict__ cand_score,
+    float* __restrict__ cand_box, float* __restrict__ cand_ldm, int* __restrict__ cand_prior,
+    int* __restrict__ cand_count, float* __restrict__ dense_score, float* __restrict__ dense_box,
+    float* __restrict__ dense_ldm) {
+  __shared__ int wave_cnt[DEC_THREADS / 64];
+  __shared__ int base_sh;
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = lv.start[3];
+  const float fw = (float)img_w, fh = (float)img_h;
+  if (tid == 0) base_sh = 0;
+  __syncthreads();
+
+  for (int p0 = 0; p0 < P; p0 += DEC_THREADS) {
+    const int p = p0 + tid;
+    bool pass = false;
+    float score = 0.f, box[4], ldm[10];
+    if (p < P) {
+      const int l = p >= lv.start[2] ? 2 : (p >= lv.start[1] ? 1 : 0);
+      const int q = p - lv.start[l];
+      const int cell = q >> 1, a = q & 1;
+      const int wl = lv.w[l], hl = lv.h[l];
+      const int i = cell / wl, j = cell - i * wl;
+      const float* hp = (l == 0 ? head0 : (l == 1 ? head1 : head2)) + ((long)img * hl * wl + cell) * 32;
+      const int step = 8 << l;
+      const double ms = (double)((16 << (2 * l)) << a);  // 16,32 | 64,128 | 256,512
+      // PriorBox: python-double arithmetic, rounded once to f32 (_layers.py:57-60)
+      const float pcx = (float)(((double)j + 0.5) * (double)step / (double)img_w);
+      const float pcy = (float)(((double)i + 0.5) * (double)step / (double)img_h);
+      const float pw = (float)(ms / (double)img_w);
+      const float ph = (float)(ms / (double)img_h);
+      // softmax over (bg, face), ATen CPU order: exp(x - max) * (1 / sum)
+      const float l0 = hp[2 * a], l1 = hp[2 * a + 1];
+      const float mx = fmaxf(l0, l1);
+      const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+      const float inv = 1.0f / (e0 + e1);
+      score = e1 * inv;
+      const float* bp = hp + 4 + 4 * a;
+      const float cx = pcx + (bp[0] * v0) * pw;
+      const float cy = pcy + (bp[1] * v0) * ph;
+      const float bw = pw * expf(bp[2] * v1);
+      const float bh = ph * expf(bp[3] * v1);
+      const float x1 = cx - bw / 2.0f, y1 = cy - bh / 2.0f;
+      const float x2 = bw + x1, y2 = bh + y1;
+      box[0] = x1 * fw; box[1] = y1 * fh; box[2] = x2 * fw; box[3] = y2 * fh;
+      const float* lp = hp + 12 + 10 * a;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        ldm[2 * k] = (pcx + (lp[2 * k] * v0) * pw) * fw;
+        ldm[2 * k + 1] = (pcy + (lp[2 * k + 1] * v0) * ph) * fh;
+      }
+      pass = score > thr;
+      if (dense_score != nullptr) {
+        const long d = (long)img * P + p;
+        dense_score[d] = score;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dense_box[d * 4 + k] = box[k];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) dense_ldm[d * 10 + k] = ldm[k];
+      }
+    }
+    const unsigned long long bal = __ballot(pass);
+    const int rank_in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int wave_base = base_sh;
+    for (int wv = 0; wv < wave; ++wv) wave_base += wave_cnt[wv];
+    if (pass) {
+      const long d = (long)img * P + wave_base + rank_in_wave;
+      cand_score[d] = score;
+      cand_prior[d] = p;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cand_box[d * 4 + k] = box[k];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) cand_ldm[d * 10 + k] = ldm[k];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = base_sh;
+      for (int wv = 0; wv < DEC_THREADS / 64; ++wv) tot += wave_cnt[wv];
+      base_sh = tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) cand_count[img] = base_sh;
+}
+
+// ---------------------------------------------------------------------------
+// sort + NMS + strategy: one workgroup per image.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void bitonic_pairs(unsigned long long* a, int npairs, int j, int k, int tid,
+                                              int nthreads, int index_base) {
+  for (int idx = tid; idx < npairs; idx += nthreads) {
+    const int i = 2 * j * (idx / j) + (idx % j);
+    const int l = i + j;
+    const bool asc = (((i + index_base) & k) == 0);
+    const unsigned long long x = a[i], y = a[l];
+    if ((x > y) == asc) { a[i] = y; a[l] = x; }
+  }
+}
+
+// reference IoU test (retinaface.py:281-292): survivor iff ovr <= thr
+__device__ __forceinline__ bool suppressed(float kx1, float ky1, float kx2, float ky2, float karea,
+                                           float x1, float y1, float x2, float y2, float area, float thr) {
+  const float xx1 = fmaxf(kx1, x1), yy1 = fmaxf(ky1, y1);
+  const float xx2 = fminf(kx2, x2), yy2 = fminf(ky2, y2);
+  const float w = fmaxf(0.0f, xx2 - xx1 + 1.0f);
+  const float h = fmaxf(0.0f, yy2 - yy1 + 1.0f);
+  const float a = w * h;
+  const float ovr = a / (karea + area - a);
+  return !(ovr <= thr);
+}
+
+__global__ void __launch_bounds__(NMS_THREADS) retina_nms_kernel(
+    const float* __restrict__ cand_score, const float* __restrict__ cand_box,
+    const int* __restrict__ cand_count, int cap, int cap_p2, float thr, int strategy,
+    unsigned long long* __restrict__ ws_keys, float* __restrict__ ws_box, int* __restrict__ keep_pos,
+    int* __restrict__ keep_count, int* __restrict__ sel_pos, int* __restrict__ sel_count) {
+  __shared__ unsigned long long lkeys[SORT_LDS_KEYS];  // sort scratch, later alive bitmap + kept boxes
+  __shared__ int s_kc;
+  __shared__ float s_best_area[NMS_THREADS / 64];
+  __shared__ int s_best_rank[NMS_THREADS / 64];
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = cand_count[img];
+  const float* score = cand_score + (long)img * cap;
+  const float4* box = reinterpret_cast<const float4*>(cand_box) + (long)img * cap;
+  int* kpos = keep_pos + (long)img * cap;
+  int* spos = sel_pos + (long)img * cap;
+  if (K <= 0) {
+    if (tid == 0) { keep_count[img] = 0; sel_count[img] = 0; }
+    return;
+  }
+  int Kp = 64;
+  while (Kp < K) Kp <<= 1;
+  unsigned long long* gkeys = ws_keys + (long)img * cap_p2;
+  float* sbox = ws_box + (long)img * cap_p2 * 5;  // x1,y1,x2,y2,area in sorted order
+
+  // ---- 1. keys: (~score bits, position) ascending == score desc, position asc
+  const bool in_lds = Kp <= SORT_LDS_KEYS;
+  unsigned long long* keys = in_lds ? lkeys : gkeys;
+  for (int i = tid; i < Kp; i += NMS_THREADS) {
+    unsigned long long kv = ~0ull;
+    if (i < K) kv = ((unsigned long long)(~__float_as_uint(score[i])) << 32) | (unsigned)i;
+    keys[i] = kv;
+  }
+  __syncthreads();
+  // ---- 2. bitonic sort
+  if (in_lds) {
+    for (int k = 2; k <= Kp; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        bitonic_pairs(keys, Kp >> 1, j, k, tid, NMS_THREADS, 0);
+        __syncthreads();
+      }
+  } else {
+    for (int k = 2; k <= Kp; k <<= 1) {
+      int j = k >> 1;
+      for (; j >= SORT_LDS_KEYS; j >>= 1) {  // strides that span LDS chunks: in global memory
+        bitonic_pairs(gkeys, Kp >> 1, j, k, tid, NMS_THREADS, 0);
+        __threadfence_block();
+        __syncthreads();
+      }
+      for (int c0 = 0; c0 < Kp; c0 += SORT_LDS_KEYS) {  // remaining strides chunk by chunk in LDS
+        for (int i = tid; i < SORT_LDS_KEYS; i += NMS_THREADS) lkeys[i] = gkeys[c0 + i];
+        __syncthreads();
+        for (int jj = j; jj > 0; jj >>= 1) {
+          bitonic_pairs(lkeys, SORT_LDS_KEYS >> 1, jj, k, tid, NMS_THREADS, c0);
+          __syncthreads();
+        }
+        for (int i = tid; i < SORT_LDS_KEYS; i += NMS_THREADS) gkeys[c0 + i] = lkeys[i];
+        __syncthreads();
+      }
+    }
+  }
+  // ---- 3. sorted boxes + areas to workspace, sorted order to gkeys (lds is reused below)
+  for (int i = tid; i < K; i += NMS_THREADS) {
+    const unsigned long long kv = keys[i];
+    const int pos = (int)(unsigned)(kv & 0xffffffffull);
+    const float4 b = box[pos];
+    const float area = (b.z - b.x + 1.0f) * (b.w - b.y + 1.0f);
+    sbox[i * 5 + 0] = b.x; sbox[i * 5 + 1] = b.y; sbox[i * 5 + 2] = b.z; sbox[i * 5 + 3] = b.w;
+    sbox[i * 5 + 4] = area;
+    if (in_lds) gkeys[i] = kv;
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- 4. tiled greedy NMS.  LDS reuse: alive bitmap (Kp/64 words) then kept-box tile.
+  unsigned long long* alive = lkeys;                       // up to 1024 words
+  float* tile = reinterpret_cast<float*>(lkeys + 1024);    // 64 * 5 floats
+  int* tile_n = reinterpret_cast<int*>(tile + 64 * 5);
+  const int nwords = Kp >> 6;
+  for (int wd = tid; wd < nwords; wd += NMS_THREADS) {
+    const int lo = wd << 6;
+    unsigned long long m = 0ull;
+    if (lo + 64 <= K) m = ~0ull;
+    else if (lo < K) m = (1ull << (K - lo)) - 1ull;
+    alive[wd] = m;
+  }
+  if (tid == 0) s_kc = 0;
+  __syncthreads();
+
+  const int ntiles = (K + 63) >> 6;
+  for (int t = 0; t < ntiles; ++t) {
+    if (wave == 0) {
+      const int c = (t << 6) + lane;
+      float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, area = 0.f;
+      if (c < K) { x1 = sbox[c * 5]; y1 = sbox[c * 5 + 1]; x2 = sbox[c * 5 + 2]; y2 = sbox[c * 5 + 3]; area = sbox[c * 5 + 4]; }
+      bool me = (alive[t] >> lane) & 1ull;
+      for (int b = 0; b < 64; ++b) {
+        const unsigned long long m = __ballot(me);
+        if (!((m >> b) & 1ull)) continue;  // wave-uniform
+        const float kx1 = __shfl(x1, b), ky1 = __shfl(y1, b), kx2 = __shfl(x2, b), ky2 = __shfl(y2, b);
+        const float ka = __shfl(area, b);
+        if (lane > b && me && suppressed(kx1, ky1, kx2, ky2, ka, x1, y1, x2, y2, area, thr)) me = false;
+      }
+      const unsigned long long m = __ballot(me);
+      const int rank = __popcll(m & ((1ull << lane) - 1ull));
+      const int kc = s_kc;
+      if (me) {
+        kpos[kc + rank] = (int)(unsigned)(gkeys[c] & 0xffffffffull);
+        tile[rank * 5 + 0] = x1; tile[rank * 5 + 1] = y1; tile[rank * 5 + 2] = x2; tile[rank * 5 + 3] = y2;
+        tile[rank * 5 + 4] = area;
+      }
+      if (lane == 0) { *tile_n = __popcll(m); s_kc = kc + __popcll(m); }
+    }
+    __syncthreads();
+    const int nk = *tile_n;
+    if (nk > 0) {
+      for (int wd = t + 1 + wave; wd < nwords && (wd << 6) < K; wd += NMS_THREADS / 64) {
+        const unsigned long long m = alive[wd];
+        if (m == 0ull) continue;  // wave-uniform
+        bool me = (m >> lane) & 1ull;
+        if (me) {
+          const int c = (wd << 6) + lane;
+          const float x1 = sbox[c * 5], y1 = sbox[c * 5 + 1], x2 = sbox[c * 5 + 2], y2 = sbox[c * 5 + 3];
+          const float area = sbox[c * 5 + 4];
+          for (int q = 0; q < nk; ++q) {
+            if (suppressed(tile[q * 5], tile[q * 5 + 1], tile[q * 5 + 2], tile[q * 5 + 3], tile[q * 5 + 4], x1,
+                           y1, x2, y2, area, thr)) { me = false; break; }
+          }
+        }
+        const unsigned long long nm = __ballot(me);
+        if (lane == 0) alive[wd] = nm;
+      }
+    }
+    __syncthreads();
+  }
+  const int kc = s_kc;
+  if (tid == 0) keep_count[img] = kc;
+
+  // ---- 5. take_by_strategy (retinaface.py:381-400)
+  if (strategy == 0) {
+    for (int i = tid; i < kc; i += NMS_THREADS) spos[i] = kpos[i];
+    if (tid == 0) sel_count[img] = kc;
+  } else if (strategy == 1) {
+    if (tid == 0) { spos[0] = kpos[0]; sel_count[img] = kc > 0 ? 1 : 0; }
+  } else {
+    // first maximum of the +1-convention area over the kept boxes (NaN counts as maximal, like torch.argmax)
+    float best = -INFINITY; int brank = 0x7fffffff; bool bnan = false;
+    __threadfence_block();
+    for (int i = tid; i < kc; i += NMS_THREADS) {
+      const float4 b = box[kpos[i]];
+      const float area = (b.z - b.x + 1.0f) * (b.w - b.y + 1.0f);
+      const bool isn = area != area;
+      if (bnan) continue;
+      if (isn) { bnan = true; best = area; brank = i; }
+      else if (brank == 0x7fffffff || area > best) { best = area; brank = i; }
+    }
+    // wave reduce: order (is_nan desc, area desc, rank asc)
+    for (int off = 32; off > 0; off >>= 1) {
+      const float oa = __shfl_down(best, off); const int orank = __shfl_down(brank, off);
+      const int on = __shfl_down((int)bnan, off);
+      bool take;
+      if (orank == 0x7fffffff) take = false;
+      else if (brank == 0x7fffffff) take = true;
+      else if (on != (int)bnan) take = on != 0;
+      else if (bnan) take = orank < brank;
+      else take = (oa > best) || (oa == best && orank < brank);
+      if (take) { best = oa; brank = orank; bnan = on != 0; }
+    }
+    if (lane == 0) { s_best_area[wave] = best; s_best_rank[wave] = bnan ? -brank - 1 : brank; }
+    __syncthreads();
+    if (tid == 0) {
+      float fb = 0.f; int fr = 0x7fffffff; bool fn = false;
+      for (int wv = 0; wv < NMS_THREADS / 64; ++wv) {
+        int rk = s_best_rank[wv]; const float ar = s_best_area[wv];
+        if (rk == 0x7fffffff) continue;
+        const bool isn = rk < 0;
+        if (isn) rk = -rk - 1;
+        bool take;
+        if (fr == 0x7fffffff) take = true;
+        else if (isn != fn) take = isn;
+        else if (isn) take = rk < fr;
+        else take = (ar > fb) || (ar == fb && rk < fr);
+        if (take) { fb = ar; fr = rk; fn = isn; }
+      }
+      if (kc > 0) { spos[0] = kpos[fr]; sel_count[img] = 1; } else sel_count[img] = 0;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) retina_gather_kernel(
+    const float* __restrict__ cand_ldm, const int* __restrict__ sel_pos, const int* __restrict__ sel_count,
+    int n, int cap, const int* __restrict__ paddings, int max_faces, int* __restrict__ face_offset,
+    float* __restrict__ out_ldm, int* __restrict__ out_img) {
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int i = 0; i < n; ++i) { face_offset[i] = acc; acc += sel_count[i]; }
+    face_offset[n] = acc;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int img = 0; img < n; ++img) {
+    const int off = face_offset[img], cnt = sel_count[img];
+    const float px = paddings ? (float)paddings[img * 4 + 2] : 0.f;  // left
+    const float py = paddings ? (float)paddings[img * 4 + 0] : 0.f;  // top
+    for (int e = threadIdx.x; e < cnt * 10; e += blockDim.x) {
+      const int k = e / 10, c = e - k * 10;
+      const int face = off + k;
+      if (face >= max_faces) continue;
+      const float v = cand_ldm[((long)img * cap + sel_pos[(long)img * cap + k]) * 10 + c];
+      out_ldm[(long)face * 10 + c] = v - ((c & 1) ? py : px);
+      if (c == 0) out_img[face] = img;
+    }
+  }
+}
+
+inline int pow2_ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+extern "C" int64_t fcp_retina_nms_workspace_bytes(int n, int cap) {
+  return (int64_t)n * pow2_ceil(cap) * (8 + 5 * 4);
+}
+
+extern "C" int fcp_retina_decode(const float* head0, const float* head1, const float* head2, int n,
+                                 int img_h, int img_w, float vis_threshold, float var0, float var1,
+                                 float* cand_score, float* cand_box, float* cand_ldm, int32_t* cand_prior,
+                                 int32_t* cand_count, float* dense_score, float* dense_box,
+                                 float* dense_ldm, fcp_stream_t stream) {
+  FCP_REQUIRE(head0 && head1 && head2, "retina_decode: null head pointer");
+  FCP_REQUIRE(cand_score && cand_box && cand_ldm && cand_prior && cand_count, "retina_decode: null output");
+  FCP_REQUIRE(n > 0 && img_h > 0 && img_w > 0, "retina_decode: bad sizes");
+  FCP_REQUIRE((dense_score == nullptr) == (dense_box == nullptr) && (dense_box == nullptr) == (dense_ldm == nullptr),
+              "retina_decode: dense outputs must be all set or all NULL");
+  Levels lv;
+  lv.start[0] = 0;
+  for (int l = 0; l < 3; ++l) {
+    const int s = 8 << l;
+    lv.h[l] = (img_h + s - 1) / s;
+    lv.w[l] = (img_w + s - 1) / s;
+    lv.start[l + 1] = lv.start[l] + 2 * lv.h[l] * lv.w[l];
+  }
+  hipLaunchKernelGGL(retina_decode_kernel, dim3(n), dim3(DEC_THREADS), 0, (hipStream_t)stream, head0, head1,
+                     head2, lv, img_h, img_w, vis_threshold, var0, var1, cand_score, cand_box, cand_ldm,
+                     cand_prior, cand_count, dense_score, dense_box, dense_ldm);
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int fcp_retina_nms_select(const float* cand_score, const float* cand_box,
+                                     const int32_t* cand_count, int n, int cap, float nms_threshold,
+                                     int strategy, void* workspace, int32_t* keep_pos, int32_t* keep_count,
+                                     int32_t* sel_pos, int32_t* sel_count, fcp_stream_t stream) {
+  FCP_REQUIRE(cand_score && cand_box && cand_count && workspace, "retina_nms: null input");
+  FCP_REQUIRE(keep_pos && keep_count && sel_pos && sel_count, "retina_nms: null output");
+  FCP_REQUIRE(n > 0 && cap > 0, "retina_nms: bad sizes");
+  FCP_REQUIRE(cap <= 65536, "retina_nms: capacity above 65536 candidates per image is not supported");
+  FCP_REQUIRE(strategy >= 0 && strategy <= 2, "Unsupported startegy: %d", strategy);
+  FCP_REQUIRE(((uintptr_t)cand_box & 15) == 0 && ((uintptr_t)workspace & 7) == 0, "retina_nms: misaligned buffers");
+  const int cap_p2 = pow2_ceil(cap);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);
+  float* sbox = reinterpret_cast<float*>(keys + (size_t)n * cap_p2);
+  hipLaunchKernelGGL(retina_nms_kernel, dim3(n), dim3(NMS_THREADS), 0, (hipStream_t)stream, cand_score,
+                     cand_box, cand_count, cap, cap_p2, nms_threshold, strategy, keys, sbox, keep_pos,
+                     keep_count, sel_pos, sel_count);
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int fcp_retina_gather_faces(const float* cand_ldm, const int32_t* sel_pos,
+                                       const int32_t* sel_count, int n, int cap, const int32_t* paddings,
+                                       int max_faces, int32_t* face_offset, float* out_ldm,
+                                       int32_t* out_img, fcp_stream_t stream) {
+  FCP_REQUIRE(cand_ldm && sel_pos && sel_count && face_offset && out_ldm && out_img, "retina_gather: null pointer");
+  FCP_REQUIRE(n > 0 && cap > 0 && max_faces > 0, "retina_gather: bad sizes");
+  hipLaunchKernelGGL(retina_gather_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cand_ldm, sel_pos,
+                     sel_count, n, cap, paddings, max_faces, face_offset, out_ldm, out_img);
+  FCP_LAUNCH_OK();
+  return 0;
+}

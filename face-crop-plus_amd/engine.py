@@ -200,6 +200,18 @@ def u8_to_nhwc4(images_u8: torch.Tensor, sub=(0.0, 0.0, 0.0), div: float = 1.0) 
     return out
 
 
+def f32nchw_to_nhwc4(images: torch.Tensor, sub=(0.0, 0.0, 0.0), div: float = 1.0) -> Act:
+    """(n,3,h,w) fp32 device tensor -> fp32 NHWC4 activation ((x - sub) / div)."""
+    assert images.dtype == torch.float32 and images.dim() == 4 and images.shape[1] == 3
+    images = images.contiguous()
+    n, _, h, w = images.shape
+    out = Act.empty(n, h, w, 4, images.device)
+    sub_arr = (C.c_float * 3)(*[float(s) for s in sub])
+    N.check(N.lib().fcp_f32nchw_to_nhwc4_f32(N.ptr(images), out.ptr(), n, h, w, sub_arr, float(div),
+                                             N.stream_ptr()), "fcp_f32nchw_to_nhwc4_f32")
+    return out
+
+
 def maxpool3x3s2(x: Act) -> Act:
     assert x.c0 == 0 and x.c == x.ld
     oh, ow = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1

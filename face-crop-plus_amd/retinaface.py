@@ -1,0 +1,215 @@
+"""RetinaFace 5-point landmark detector on MI355X (mirror of the reference's
+``models/retinaface.py`` interface: ``RetinaFace(strategy, vis).load(device)``,
+``.predict(images) -> (ndarray (F,5,2) f32, list[int])``; tunables
+``nms_threshold`` / ``variance`` / ``vis_threshold`` / ``strategy`` stay plain
+attributes, retinaface.py:87-90).
+
+Every layer is one ``fcp_conv2d_nhwc_f32`` launch (BatchNorm folded, ReLU /
+residual / FPN top-down add fused); SSH's three-way concat and the three heads
+are realised as channel slices of shared NHWC buffers; decode / threshold /
+compaction / sort / NMS / strategy run in three more kernels, nothing of the
+data path touches the host before the final landmark copy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import engine as E
+from .weights import load_state_dict
+
+STRATEGIES = {"all": 0, "best": 1, "largest": 2}
+
+
+class RetinaFace:
+    WEIGHTS_FILENAME = "retinaface_detector.pth"
+
+    def __init__(self, strategy: str = "all", vis: float = 0.6):
+        self.strategy = strategy
+        self.vis_threshold = vis
+        self.nms_threshold = 0.4
+        self.variance = [0.1, 0.2]
+        self.device = None
+        self._p = None
+
+    # ------------------------------------------------------------------ load
+    def load(self, device: str | torch.device = "cuda:0", weights=None):
+        """Pack the state dict for the HIP engine (reference ``LoadMixin.load``,
+        _layers.py:16-25).  ``weights``: None (real checkpoint if present, else the
+        deterministic generator), a path, a state dict, or "generated"."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("face_crop_plus_amd runs on an AMD GPU only (device must be cuda:N / hip); "
+                               "there is no CPU fallback")
+        N.lib()  # fail loudly now if the extension is missing
+        self.device = device
+        sd = load_state_dict("retinaface", weights)
+        with torch.cuda.device(device):
+            self._p = self._pack(sd, device)
+        return self
+
+    @staticmethod
+    def _pack(sd, dev):
+        p = {}
+        pc, bn = E.pack_conv, E.bn_of
+        # stem: kernel keeps RGB channel order, so swap the filter's input channels (BGR) instead
+        p["stem"] = pc(sd["body.conv1.weight"], None, bn(sd, "body.bn1"), 2, 3, dev, cin_perm=[2, 1, 0])
+        blocks = []
+        for li, nb in enumerate((3, 4, 6, 3), 1):
+            for b in range(nb):
+                pre = f"body.layer{li}.{b}"
+                stride = 2 if (b == 0 and li > 1) else 1
+                blk = {
+                    "c1": pc(sd[pre + ".conv1.weight"], None, bn(sd, pre + ".bn1"), 1, 0, dev),
+                    "c2": pc(sd[pre + ".conv2.weight"], None, bn(sd, pre + ".bn2"), stride, 1, dev),
+                    "c3": pc(sd[pre + ".conv3.weight"], None, bn(sd, pre + ".bn3"), 1, 0, dev),
+                    "ds": None, "feat": (b == nb - 1 and li >= 2),
+                }
+                if (pre + ".downsample.0.weight") in sd:
+                    blk["ds"] = pc(sd[pre + ".downsample.0.weight"], None, bn(sd, pre + ".downsample.1"),
+                                   stride, 0, dev)
+                blocks.append(blk)
+        p["blocks"] = blocks
+        for i in (1, 2, 3):
+            p[f"fpn.output{i}"] = pc(sd[f"fpn.output{i}.0.weight"], None, bn(sd, f"fpn.output{i}.1"), 1, 0, dev)
+        for i in (1, 2):
+            p[f"fpn.merge{i}"] = pc(sd[f"fpn.merge{i}.0.weight"], None, bn(sd, f"fpn.merge{i}.1"), 1, 1, dev)
+        # SSH buffer layout per level (384 ch): [B c5_1 (64) | A c3 (128) | E c7 (64) | C c5 (64) | D c7_2 (64)]
+        head_perm = list(range(0, 128)) + list(range(192, 256)) + list(range(128, 192))  # reads [A | E | C]
+        for k in (1, 2, 3):
+            def folded(nm):
+                return E.fold_bn(sd[f"ssh{k}.{nm}.0.weight"].numpy(), {q: v.numpy() for q, v in bn(sd, f"ssh{k}.{nm}.1").items()}, None)
+            w_b, b_b = folded("conv5X5_1")
+            w_a, b_a = folded("conv3X3")
+            p[f"ssh{k}.ab"] = pc(np.concatenate([w_b, w_a]), np.concatenate([b_b, b_a]), None, 1, 1, dev)
+            w_c, b_c = folded("conv5X5_2")
+            w_d, b_d = folded("conv7X7_2")
+            p[f"ssh{k}.cd"] = pc(np.concatenate([w_c, w_d]), np.concatenate([b_c, b_d]), None, 1, 1, dev)
+            w_e, b_e = folded("conv7x7_3")
+            p[f"ssh{k}.e"] = pc(w_e, b_e, None, 1, 1, dev)
+            i = k - 1
+            hw = np.concatenate([sd[f"{h}.{i}.conv1x1.weight"].numpy() for h in ("ClassHead", "BboxHead", "LandmarkHead")])
+            hb = np.concatenate([sd[f"{h}.{i}.conv1x1.bias"].numpy() for h in ("ClassHead", "BboxHead", "LandmarkHead")])
+            p[f"head{k}"] = pc(hw, hb, None, 1, 0, dev, cin_perm=head_perm)
+        return p
+
+    # --------------------------------------------------------------- forward
+    def forward_heads(self, x4: E.Act):
+        """NHWC4 (RGB - mean) -> three fused head maps (n, h/8|16|32, w/.., 32)."""
+        p = self._p
+        x = E.conv(p["stem"], x4, act_slope=0.0)
+        x = E.maxpool3x3s2(x)
+        feats = []
+        for blk in p["blocks"]:
+            o = E.conv(blk["c1"], x, act_slope=0.0)
+            o = E.conv(blk["c2"], o, act_slope=0.0)
+            idt = x if blk["ds"] is None else E.conv(blk["ds"], x)
+            x = E.conv(blk["c3"], o, act_slope=0.0, res1=idt, res1_pre=True)
+            if blk["feat"]:
+                feats.append(x)
+        # FPN (_layers.py:127-145): LeakyReLU slope 0 == ReLU for 256 channels
+        o3 = E.conv(p["fpn.output3"], feats[2], act_slope=0.0)
+        o2 = E.conv(p["fpn.output2"], feats[1], act_slope=0.0, res1=o3, res1_pre=False)
+        o2 = E.conv(p["fpn.merge2"], o2, act_slope=0.0)
+        o1 = E.conv(p["fpn.output1"], feats[0], act_slope=0.0, res1=o2, res1_pre=False)
+        o1 = E.conv(p["fpn.merge1"], o1, act_slope=0.0)
+        heads = []
+        for k, f in zip((1, 2, 3), (o1, o2, o3)):
+            s = E.Act.empty(f.n, f.h, f.w, 384, f.buf.device)
+            E.conv(p[f"ssh{k}.ab"], f, s.slice(0, 192), act_slope=0.0)
+            E.conv(p[f"ssh{k}.cd"], s.slice(0, 64), s.slice(256, 128), act_slope=0.0)
+            E.conv(p[f"ssh{k}.e"], s.slice(320, 64), s.slice(192, 64), act_slope=0.0)
+            heads.append(E.conv(p[f"head{k}"], s.slice(64, 256)))
+        return heads
+
+    # ---------------------------------------------------------------- detect
+    def detect(self, images_u8: torch.Tensor | None = None, *, x4: E.Act | None = None,
+               paddings: torch.Tensor | None = None, max_faces: int | None = None, want_dense: bool = False):
+        """Device-resident detection.  ``images_u8``: (n,h,w,3) uint8 RGB on the GPU.
+
+        Returns a dict of device tensors: ``landmarks`` (max_faces,5,2) f32 (padding
+        already subtracted), ``img_idx`` (max_faces,) i32, ``face_offset`` (n+1,) i32
+        (``face_offset[n]`` = number of faces), plus the candidate / keep arrays.
+        """
+        if self.strategy not in STRATEGIES:
+            raise ValueError(f"Unsupported startegy: {self.strategy}")
+        if x4 is None:
+            # RGB order is kept; means are (R,G,B) = (123,117,104) (retinaface.py:450)
+            x4 = E.u8_to_nhwc4(images_u8, sub=(123.0, 117.0, 104.0))
+        n, h, w = x4.n, x4.h, x4.w
+        dev = x4.buf.device
+        heads = self.forward_heads(x4)
+        P = sum(2 * (-(-h // s)) * (-(-w // s)) for s in (8, 16, 32))
+        f32, i32 = torch.float32, torch.int32
+        cand_score = torch.empty((n, P), dtype=f32, device=dev)
+        cand_box = torch.empty((n, P, 4), dtype=f32, device=dev)
+        cand_ldm = torch.empty((n, P, 10), dtype=f32, device=dev)
+        cand_prior = torch.empty((n, P), dtype=i32, device=dev)
+        cand_count = torch.empty((n,), dtype=i32, device=dev)
+        dense = (None, None, None)
+        if want_dense:
+            dense = (torch.empty((n, P), dtype=f32, device=dev), torch.empty((n, P, 4), dtype=f32, device=dev),
+                     torch.empty((n, P, 10), dtype=f32, device=dev))
+        st = N.stream_ptr()
+        lib = N.lib()
+        N.check(lib.fcp_retina_decode(heads[0].ptr(), heads[1].ptr(), heads[2].ptr(), n, h, w,
+                                      float(self.vis_threshold), float(self.variance[0]), float(self.variance[1]),
+                                      N.ptr(cand_score), N.ptr(cand_box), N.ptr(cand_ldm), N.ptr(cand_prior),
+                                      N.ptr(cand_count), N.ptr(dense[0]), N.ptr(dense[1]), N.ptr(dense[2]), st),
+                "fcp_retina_decode")
+        out = nms_select(cand_score, cand_box, cand_count, self.nms_threshold, self.strategy)
+        if max_faces is None:
+            max_faces = n if self.strategy != "all" else int(out["sel_count"].sum().item())
+        max_faces = max(int(max_faces), 1)
+        landmarks = torch.zeros((max_faces, 5, 2), dtype=f32, device=dev)
+        img_idx = torch.zeros((max_faces,), dtype=i32, device=dev)
+        face_offset = torch.empty((n + 1,), dtype=i32, device=dev)
+        if paddings is not None:
+            paddings = paddings.to(device=dev, dtype=i32).contiguous()
+        N.check(lib.fcp_retina_gather_faces(N.ptr(cand_ldm), N.ptr(out["sel_pos"]), N.ptr(out["sel_count"]), n, P,
+                                            N.ptr(paddings), max_faces, N.ptr(face_offset), N.ptr(landmarks),
+                                            N.ptr(img_idx), st), "fcp_retina_gather_faces")
+        out.update(landmarks=landmarks, img_idx=img_idx, face_offset=face_offset, cand_score=cand_score,
+                   cand_box=cand_box, cand_ldm=cand_ldm, cand_prior=cand_prior, cand_count=cand_count,
+                   heads=heads, dense=dense, max_faces=max_faces)
+        return out
+
+    # --------------------------------------------------------------- predict
+    @torch.no_grad()
+    def predict(self, images: torch.Tensor):
+        """Reference signature (retinaface.py:411-470): ``images`` (N,3,H,W) float
+        RGB 0..255 (or (N,H,W,3) uint8) -> ((F,5,2) float32 ndarray, list[int])."""
+        with torch.cuda.device(self.device):
+            if images.dtype == torch.uint8:
+                res = self.detect(images.to(self.device).contiguous())
+            else:
+                x4 = E.f32nchw_to_nhwc4(images.to(self.device, torch.float32), sub=(123.0, 117.0, 104.0))
+                res = self.detect(x4=x4)
+            nf = int(res["face_offset"][-1].item())
+            nf = min(nf, res["max_faces"])
+            landmarks = res["landmarks"][:nf].cpu().numpy()
+            indices = res["img_idx"][:nf].cpu().numpy().astype(np.int64).tolist()
+        return landmarks, indices
+
+
+def nms_select(cand_score, cand_box, cand_count, nms_threshold=0.4, strategy="all"):
+    """Sort + greedy NMS + take_by_strategy on device (retinaface.py:270-304, :363-408)."""
+    if strategy not in STRATEGIES:
+        raise ValueError(f"Unsupported startegy: {strategy}")
+    n, cap = cand_score.shape
+    dev = cand_score.device
+    i32 = torch.int32
+    lib = N.lib()
+    ws = torch.empty((int(lib.fcp_retina_nms_workspace_bytes(n, cap)),), dtype=torch.uint8, device=dev)
+    keep_pos = torch.empty((n, cap), dtype=i32, device=dev)
+    keep_count = torch.empty((n,), dtype=i32, device=dev)
+    sel_pos = torch.empty((n, cap), dtype=i32, device=dev)
+    sel_count = torch.empty((n,), dtype=i32, device=dev)
+    N.check(lib.fcp_retina_nms_select(N.ptr(cand_score), N.ptr(cand_box), N.ptr(cand_count), n, cap,
+                                      float(nms_threshold), STRATEGIES[strategy], N.ptr(ws), N.ptr(keep_pos),
+                                      N.ptr(keep_count), N.ptr(sel_pos), N.ptr(sel_count), N.stream_ptr()),
+            "fcp_retina_nms_select")
+    return dict(keep_pos=keep_pos, keep_count=keep_count, sel_pos=sel_pos, sel_count=sel_count)

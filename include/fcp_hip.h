@@ -88,6 +88,11 @@ int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);
 int fcp_u8_to_nhwc4_f32(const uint8_t* in, float* out, int64_t npix,
                         const float* sub_host, float div, fcp_stream_t stream);
 
+/* Same, from the reference API's float tensor: fp32 NCHW (n,3,h,w) -> fp32 NHWC4
+ * (RetinaFace.predict / RRDBNet.predict take float NCHW, retinaface.py:411, rrdb.py:84). */
+int fcp_f32nchw_to_nhwc4_f32(const float* in, float* out, int n, int h, int w,
+                             const float* sub_host, float div, fcp_stream_t stream);
+
 /* MaxPool2d(kernel 3, stride 2, pad 1) on NHWC fp32 (torchvision ResNet stem,
  * _layers.py:247).  c % 4 == 0. */
 int fcp_maxpool3x3s2_nhwc_f32(const float* in, float* out, int n, int h, int w, int c,
@@ -121,10 +126,11 @@ int fcp_retina_decode(const float* head0, const float* head1, const float* head2
  * reference's +1-pixel IoU and `ovr <= nms_threshold` survival rule
  * (retinaface.py:270-298), followed by take_by_strategy (retinaface.py:363-408).
  * strategy: 0 = all, 1 = best, 2 = largest.
- * workspace: n * cap * 8 bytes (sort keys), cap = candidate capacity (stride of
- * the cand_* arrays).  Outputs: keep_pos (n,cap) int32 = candidate positions of
+ * workspace: fcp_retina_nms_workspace_bytes(n, cap) bytes (sort keys + sorted
+ * boxes), cap = candidate capacity (stride of the cand_* arrays, <= 65536).  Outputs: keep_pos (n,cap) int32 = candidate positions of
  * the kept boxes in keep order, keep_count (n); sel_pos (n,cap) / sel_count (n)
  * = the positions take_by_strategy selects (for "all" identical to keep). */
+int64_t fcp_retina_nms_workspace_bytes(int n, int cap);
 int fcp_retina_nms_select(const float* cand_score, const float* cand_box,
                           const int32_t* cand_count, int n, int cap,
                           float nms_threshold, int strategy, void* workspace,

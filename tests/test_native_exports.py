@@ -1,0 +1,50 @@
+"""The C-ABI library builds, loads and exports every symbol include/fcp_hip.h declares
+(no compute calls: there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    import __graft_entry__ as ge
+    ge.build()
+    from face_crop_plus_amd import _native as N
+    assert os.path.isfile(N.LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "fcp_hip.h")).read()
+    declared = set(re.findall(r"\b(fcp_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"fcp_last_error"} - declared
+    lib = ctypes.CDLL(N.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"symbols declared in fcp_hip.h but not exported: {missing}"
+    assert set(N.EXPORTS) <= declared | {"fcp_abi_version", "fcp_last_error"}
+    lib.fcp_abi_version.restype = ctypes.c_int
+    assert lib.fcp_abi_version() == N.ABI_VERSION
+
+
+def test_conv_desc_layout_matches_header():
+    """ctypes mirror and the C struct must agree field by field."""
+    from face_crop_plus_amd import _native as N
+    hdr = open(os.path.join(ROOT, "include", "fcp_hip.h")).read()
+    body = hdr[hdr.index("typedef struct fcp_conv_desc {"):hdr.index("} fcp_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = re.sub(r"^(const\s+)?(float|int32_t)\s*\*?", "", decl)
+        fields += [n.strip().lstrip("*") for n in names.split(",")]
+    mine = [f[0].rstrip("_") for f in N.ConvDesc._fields_]
+    assert fields == mine
+    assert ctypes.sizeof(N.ConvDesc) == 6 * 8 + 24 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from face_crop_plus_amd import _native as N
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", str(tmp_path / "nope.so"))
+    import pytest
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        N.lib()

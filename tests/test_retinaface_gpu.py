@@ -1,0 +1,83 @@
+"""End-to-end RetinaFace on the HIP engine vs the oracle and the reference's golden predictions.
+Tolerance: landmarks within 1e-3 px (north-star), selected image indices identical."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import retinaface_ref as R
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def sd():
+    from face_crop_plus_amd import weights
+    return weights.generate_state_dict("retinaface")
+
+
+def test_heads_match_reference_golden(sd, device):
+    from face_crop_plus_amd.retinaface import RetinaFace
+    from face_crop_plus_amd import engine as E
+    d = np.load(os.path.join(G, "retina_full.npz"))
+    det = RetinaFace("all", 0.6).load(device, sd)
+    img = torch.from_numpy(d["image"]).to(device)
+    heads = det.forward_heads(E.u8_to_nhwc4(img, sub=(123.0, 117.0, 104.0)))
+    torch.cuda.synchronize()
+    n = img.shape[0]
+    cls = np.concatenate([hd.buf[..., 0:4].reshape(n, -1, 2).cpu().numpy() for hd in heads], 1)
+    loc = np.concatenate([hd.buf[..., 4:12].reshape(n, -1, 4).cpu().numpy() for hd in heads], 1)
+    ldm = np.concatenate([hd.buf[..., 12:32].reshape(n, -1, 10).cpu().numpy() for hd in heads], 1)
+    prob = torch.softmax(torch.from_numpy(cls), -1).numpy()
+    # fp32 MFMA == fmaf chain: only the summation order differs from ATen
+    assert np.abs(prob - d["prob"]).max() < 2e-5
+    assert np.abs(loc - d["loc"]).max() < 1e-4
+    assert np.abs(ldm - d["ldm"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("strat,thr", [("all", 0.6), ("best", 0.6), ("largest", 0.6), ("all", 0.5)])
+def test_predict_matches_reference_golden(strat, thr, sd, device):
+    from face_crop_plus_amd.retinaface import RetinaFace
+    d = np.load(os.path.join(G, "retina_full.npz"))
+    det = RetinaFace(strat, thr).load(device, sd)
+    x = torch.from_numpy(d["image"]).permute(0, 3, 1, 2).float()
+    lm, idx = det.predict(x)                       # reference signature: float NCHW
+    assert idx == d[f"pred_{strat}_{thr}_indices"].tolist()
+    assert lm.dtype == np.float32 and lm.shape == d[f"pred_{strat}_{thr}_landmarks"].shape
+    assert np.abs(lm - d[f"pred_{strat}_{thr}_landmarks"]).max() < 1e-3
+    lm2, idx2 = det.predict(torch.from_numpy(d["image"]))   # uint8 NHWC fast path
+    assert idx2 == idx and np.array_equal(lm, lm2)
+
+
+def test_predict_vs_oracle_nonsquare_with_padding(sd, device):
+    from face_crop_plus_amd.retinaface import RetinaFace
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (3, 200, 136, 3), generator=g, dtype=torch.uint8)   # not a multiple of 32
+    det = RetinaFace("all", 0.55).load(device, sd)
+    pads = torch.tensor([[0, 0, 0, 0], [5, 6, 0, 0], [0, 0, 7, 8]], dtype=torch.int32)
+    res = det.detect(img.to(device), paddings=pads)
+    nf = int(res["face_offset"][-1].item())
+    lm = res["landmarks"][:nf].cpu().numpy()
+    idx = res["img_idx"][:nf].cpu().tolist()
+    lm_ref, idx_ref, extra = R.predict(img.permute(0, 3, 1, 2).float(), sd, "all", 0.55, return_all=True)
+    assert nf > 0 and idx == idx_ref
+    lm_ref = lm_ref - pads.numpy()[idx_ref][:, None, [2, 0]]
+    assert np.abs(lm - lm_ref).max() < 1e-3
+    # the ordering inside NMS is only well defined when scores are not within float noise of each other
+    s = np.sort(extra["scores"][extra["scores"] > 0.55])
+    print("min score gap among candidates:", np.diff(s).min() if len(s) > 1 else None)
+
+
+def test_zero_faces(sd, device):
+    from face_crop_plus_amd.retinaface import RetinaFace
+    det = RetinaFace("largest", 0.9999).load(device, sd)
+    lm, idx = det.predict(torch.zeros((1, 64, 64, 3), dtype=torch.uint8))
+    assert lm.shape == (0, 5, 2) and idx == []
+
+
+def test_cpu_device_is_refused(sd):
+    from face_crop_plus_amd.retinaface import RetinaFace
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        RetinaFace().load("cpu", sd)
