@@ -1,0 +1,196 @@
+"""Headline benchmark: faces/sec end-to-end (detect + align + crop) on synthetic batches.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch that is already
+resident in HBM: uint8 NHWC images -> RetinaFace (fp32 MFMA convs) -> decode /
+NMS / strategy -> 5-point similarity -> warpAffine crops (uint8, on device).
+Workload at N=1 is BASELINE.json configs[1]: batch 64, 640x640, strategy
+"largest", det_threshold 0.6, output 256x256.  Multi-GPU: every rank owns an
+independent batch (weak scaling, no data-path collective); weights are
+broadcast once from rank 0 over RCCL.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (conv
+engine, fp32 MFMA peak) and `cpu_baseline` (the oracle timed on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+RETINA_GFLOP_1024 = 226.64      # algorithmic FLOP / image @1024^2 (scales with H*W)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--out-size", type=int, default=256)
+    ap.add_argument("--strategy", default="largest")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    return ap.parse_args()
+
+
+def broadcast_state_dict(sd, rank, world, dev):
+    """Rank 0's weights -> every rank, one flat fp32 RCCL broadcast over xGMI."""
+    import torch.distributed as dist
+    keys = sorted(k for k in sd if not k.endswith("num_batches_tracked"))
+    flat = torch.cat([sd[k].reshape(-1).float() for k in keys]).to(dev)
+    if rank != 0:
+        flat.zero_()
+    dist.broadcast(flat, src=0)
+    out, off = dict(sd), 0
+    flat = flat.cpu()
+    for k in keys:
+        n = sd[k].numel()
+        out[k] = flat[off:off + n].reshape(sd[k].shape).clone()
+        off += n
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from face_crop_plus_amd import weights, align, engine as E
+    from face_crop_plus_amd.retinaface import RetinaFace
+
+    sd = weights.generate_state_dict("retinaface")
+    if world > 1:
+        sd = broadcast_state_dict(sd, rank, world, dev)
+    det = RetinaFace(args.strategy, 0.6).load(dev, sd)
+    from face_crop_plus_amd.cropper import landmarks_target
+    tgt = torch.from_numpy(landmarks_target((args.out_size, args.out_size), 0.65)).to(dev)
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    images = torch.randint(0, 256, (args.batch, args.size, args.size, 3), generator=g, dtype=torch.uint8).to(dev)
+    face_total = torch.zeros((), dtype=torch.int64, device=dev)
+
+    def step(count=True):
+        res = det.detect(images, max_faces=args.batch if args.strategy != "all" else None)
+        crops, ok, _ = align.crop_align(images, res["img_idx"], res["landmarks"], tgt,
+                                        (args.out_size, args.out_size), 0)
+        if count:
+            nf = torch.clamp(res["face_offset"][-1].to(torch.int64), max=res["max_faces"])
+            valid = (torch.arange(res["max_faces"], device=dev) < nf) & (ok != 0)
+            face_total.add_(valid.sum())
+        return crops
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    faces = face_total.clone()
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(faces, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    total_faces = int(faces.item())
+
+    # ---- roofline of the dominant kernel (conv engine): per-launch HIP events on the launch stream
+    roofline = None
+    if rank == 0:
+        E.ConvStats.timing = []
+        step(False)
+        torch.cuda.synchronize()
+        conv_ms = sum(a.elapsed_time(b) for a, b, _ in E.ConvStats.timing)
+        conv_flops = sum(f for _, _, f in E.ConvStats.timing)
+        launches = len(E.ConvStats.timing)
+        E.ConvStats.timing = None
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": launches, "algorithmic_gflop_per_step": round(conv_flops / 1e9, 2),
+                    "avg_launch_ms": round(conv_ms / launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(sd, images[:32].cpu(), args, tgt.cpu().numpy())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "faces/sec end-to-end (detect+align+crop)",
+            "value": round(total_faces / elapsed, 2), "unit": "faces/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (uniform uint8 images resident in HBM; seeded random-init weights; file I/O excluded)",
+            "config": {"workload": f"RetinaFace detect + 5-pt align/crop, batch={args.batch}/GPU synthetic "
+                                   f"{args.size}x{args.size} RGB, strategy={args.strategy}, det_threshold=0.6, "
+                                   f"output {args.out_size}x{args.out_size}",
+                       "global_batch": args.batch * world, "image_size": args.size, "parallelism": f"dp{world}",
+                       "faces_per_step": total_faces / max(args.steps, 1),
+                       "images_per_s": round(args.batch * world * args.steps / elapsed, 2)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(sd, images_u8, args, tgt):
+    """The oracle (CPU restatement of the reference path, kind="port") on a bounded
+    sample of the same workload, all host cores."""
+    from oracle import retinaface_ref as R, align_ref as A
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = images_u8.permute(0, 3, 1, 2).float()
+
+    def run(k):
+        t = time.perf_counter()
+        lm, idx = R.predict(x[:k], sd, args.strategy, 0.6)
+        crops = A.crop_align(images_u8[:k].numpy(), None, idx, lm, tgt, (args.out_size, args.out_size), "constant")
+        return time.perf_counter() - t, len(crops)
+
+    t1, _ = run(1)                       # warm-up + per-image cost estimate
+    k = int(max(2, min(images_u8.shape[0], args.cpu_seconds / max(t1, 1e-3))))
+    t, nf = run(k)
+    return {"value": round(nf / t, 3), "unit": "faces/s", "cores": cores, "kind": "port",
+            "sample": f"{k} images of the same synthetic {args.size}x{args.size} batch, torch-CPU fp32 + numpy oracle, "
+                      f"{t:.1f} s wall"}
+
+
+if __name__ == "__main__":
+    main()

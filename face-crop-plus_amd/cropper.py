@@ -1,0 +1,267 @@
+"""``Cropper`` — same constructor, attributes and ``process_dir`` / ``process_batch`` /
+``crop_align`` surface as the reference (cropper.py:139-156, :441-447, :748, :852-857),
+with the batch kept resident on the GPU from the upload to the final crops:
+detect -> [enhance] -> estimate + warp -> [parse] run as HIP kernels; the host sees
+only the uint8 crops / masks it has to write to disk.
+"""
+from __future__ import annotations
+
+import os
+from collections import defaultdict
+from functools import partial
+from multiprocessing.pool import ThreadPool
+
+import numpy as np
+import torch
+
+from . import align
+from .utils import (as_batch, get_ldm_slices, parse_landmarks_file, read_images, write_image)
+
+
+def landmarks_target(output_size, face_factor):
+    """Target 5-point set (cropper.py:423-439): float32 table scaled in place."""
+    std = align.STANDARD_LANDMARKS_5.copy()
+    std[:, 0] *= output_size[0] * face_factor
+    std[:, 1] *= output_size[1] * face_factor
+    std[:, 0] += (1 - face_factor) * output_size[0] / 2
+    std[:, 1] += (1 - face_factor) * output_size[1] / 2
+    return std
+
+
+class Cropper:
+    def __init__(
+        self,
+        output_size: int | tuple[int, int] | list[int] = 256,
+        output_format: str | None = None,
+        resize_size: int | tuple[int, int] | list[int] = 1024,
+        face_factor: float = 0.65,
+        strategy: str = "largest",
+        padding: str = "constant",
+        allow_skew: bool = False,
+        landmarks: str | tuple[np.ndarray, np.ndarray] | None = None,
+        attr_groups: dict[str, list[int]] | None = None,
+        mask_groups: dict[str, list[int]] | None = None,
+        det_threshold: float | None = 0.6,
+        enh_threshold: float | None = None,
+        batch_size: int = 8,
+        num_processes: int = 1,
+        device: str | torch.device = "cuda:0",
+        weights: dict | None = None,
+    ):
+        """Arguments as in the reference (cropper.py:139-156).  ``device`` must be a GPU
+        (``"cuda:N"``); ``weights`` optionally maps "retinaface"/"rrdb"/"bisenet" to a
+        state dict / path / "generated" (default: real checkpoints when present in
+        ``$FCP_WEIGHTS_DIR`` or the torch hub cache, else the seeded generator)."""
+        self.output_size = output_size
+        self.output_format = output_format
+        self.resize_size = resize_size
+        self.face_factor = face_factor
+        self.strategy = strategy
+        self.padding = padding
+        self.allow_skew = allow_skew
+        self.landmarks = landmarks
+        self.attr_groups = attr_groups
+        self.mask_groups = mask_groups
+        self.det_threshold = det_threshold
+        self.enh_threshold = enh_threshold
+        self.batch_size = batch_size
+        self.num_processes = num_processes
+        self.device = device
+        self.weights = weights or {}
+        self.num_std_landmarks = 5
+
+        if isinstance(self.output_size, int):
+            self.output_size = (self.output_size, self.output_size)
+        if len(self.output_size) == 1:
+            self.output_size = (self.output_size[0], self.output_size[0])
+        if isinstance(self.resize_size, int):
+            self.resize_size = (self.resize_size, self.resize_size)
+        if len(self.resize_size) == 1:
+            self.resize_size = (self.resize_size[0], self.resize_size[0])
+        if isinstance(self.device, str):
+            self.device = torch.device("cuda:0" if device in ("cuda", "hip") else device.replace("hip", "cuda"))
+        if isinstance(self.landmarks, str):
+            self.landmarks = parse_landmarks_file(self.landmarks)
+
+        self._init_models()
+        self._init_landmarks_target()
+
+    # ------------------------------------------------------------------ init
+    def _init_models(self):
+        """cropper.py:346-390.  One immutable model set per Cropper (the reference
+        re-creates them in every pool thread on the shared ``self``)."""
+        self.det_model = None
+        self.enh_model = None
+        self.par_model = None
+        if self.device.type != "cuda":
+            raise RuntimeError("face_crop_plus_amd: device must be an AMD GPU ('cuda:N'); no CPU fallback")
+        if self.device.index is not None:
+            torch.cuda.set_device(self.device.index)
+        if self.det_threshold is not None and self.landmarks is None:
+            from .retinaface import RetinaFace
+            self.det_model = RetinaFace(self.strategy, self.det_threshold)
+            self.det_model.load(self.device, self.weights.get("retinaface"))
+        if self.enh_threshold is not None:
+            from .rrdb import RRDBNet
+            self.enh_model = RRDBNet(self.enh_threshold)
+            self.enh_model.load(self.device, self.weights.get("rrdb"))
+        if self.attr_groups is not None or self.mask_groups is not None:
+            from .bise import BiSeNet
+            self.par_model = BiSeNet(self.attr_groups, self.mask_groups, self.batch_size)
+            self.par_model.load(self.device, self.weights.get("bisenet"))
+
+    def _init_landmarks_target(self):
+        if self.num_std_landmarks != 5:
+            raise ValueError(f"Unsupported number of standard landmarks for estimating alignment transform "
+                             f"matrix: {self.num_std_landmarks}.")
+        self.landmarks_target = landmarks_target(self.output_size, self.face_factor)
+
+    # ------------------------------------------------------------ crop_align
+    def _crop_align_device(self, images_dev, paddings, indices, landmarks_dev):
+        """Device tensors in, (crops (F,oh,ow,3) u8 device, ok (F,) i32 device) out."""
+        pads = None if paddings is None else torch.as_tensor(np.asarray(paddings), dtype=torch.int32)
+        idx = indices if isinstance(indices, torch.Tensor) else torch.as_tensor(np.asarray(indices), dtype=torch.int32)
+        crops, ok, _ = align.crop_align(images_dev, idx, landmarks_dev, self.landmarks_target, self.output_size,
+                                        align.border_code(self.padding), self.allow_skew, pads)
+        return crops, ok
+
+    def crop_align(self, images, padding, indices, landmarks_source) -> np.ndarray:
+        """Reference signature (cropper.py:441-552): numpy in, numpy out.  ``images`` is an
+        (N,H,W,3) uint8 array or a list of differently-sized arrays."""
+        if len(indices) == 0:
+            return np.array([])
+        lms = torch.from_numpy(np.ascontiguousarray(landmarks_source, dtype=np.float32))
+        outs = []
+        if isinstance(images, np.ndarray) and images.ndim == 4:
+            dev_imgs = torch.from_numpy(np.ascontiguousarray(images)).to(self.device)
+            crops, ok = self._crop_align_device(dev_imgs, padding, list(indices), lms.to(self.device))
+            crops, ok = crops.cpu().numpy(), ok.cpu().numpy()
+            outs = [c for c, o in zip(crops, ok) if o]
+        else:
+            # ragged list: one upload + one launch per source image, face order preserved
+            order = defaultdict(list)
+            for li, ii in enumerate(indices):
+                order[int(ii)].append(li)
+            res = {}
+            for ii, lis in order.items():
+                dev_img = torch.from_numpy(np.ascontiguousarray(images[ii])).to(self.device)[None]
+                pad = None if padding is None else np.asarray(padding)[ii:ii + 1]
+                crops, ok = self._crop_align_device(dev_img, pad, [0] * len(lis), lms[lis].to(self.device))
+                for li, c, o in zip(lis, crops.cpu().numpy(), ok.cpu().numpy()):
+                    if o:
+                        res[li] = c
+            outs = [res[li] for li in sorted(res)]
+        return np.stack(outs) if len(outs) > 0 else np.array(outs)
+
+    # ----------------------------------------------------------------- saving
+    def save_group(self, faces, file_names, output_dir: str):
+        """cropper.py:554-609 (PIL writer; arrays are already RGB)."""
+        if len(faces) == 0:
+            return
+        os.makedirs(output_dir, exist_ok=True)
+        file_name_counts = defaultdict(lambda: -1)
+        for face, file_name in zip(faces, file_names):
+            name, ext = os.path.splitext(str(file_name))
+            if self.output_format is not None:
+                ext = "." + self.output_format
+            if self.strategy == "all":
+                file_name_counts[file_name] += 1
+                name += f"_{file_name_counts[file_name]}"
+            write_image(os.path.join(output_dir, name + ext), np.asarray(face))
+
+    def save_groups(self, faces, file_names, output_dir, attr_groups, mask_groups):
+        """cropper.py:611-746: attr x mask cross product of sub-directories."""
+        if attr_groups is None:
+            attr_groups = {"": list(range(len(faces)))}
+        if mask_groups is None:
+            mask_groups = {"": (list(range(len(faces))), None)}
+        for attr_name, attr_indices in attr_groups.items():
+            for mask_name, (mask_indices, masks) in mask_groups.items():
+                group_idx = list(set(attr_indices) & set(mask_indices))
+                group_dir = os.path.join(output_dir, attr_name, mask_name)
+                face_group = [faces[idx] for idx in group_idx]
+                file_name_group = file_names[group_idx]
+                self.save_group(face_group, file_name_group, group_dir)
+                if masks is not None:
+                    group_dir += "_mask"
+                    sel = masks[[list(mask_indices).index(i) for i in group_idx]]
+                    self.save_group(sel, file_name_group, group_dir)
+
+    # ------------------------------------------------------------- processing
+    @torch.no_grad()
+    def process_batch(self, file_names, input_dir: str, output_dir: str):
+        """cropper.py:748-850."""
+        images, file_names = read_images(file_names, input_dir)
+        if len(images) == 0:
+            return
+        paddings, landmarks, indices, images_dev = None, None, None, None
+        with torch.cuda.device(self.device):
+            if self.landmarks is None and self.det_model is None:
+                indices = list(range(len(file_names)))
+            elif self.landmarks is not None:
+                indices, indices_ldm = [], []
+                for i, file_name in enumerate(file_names):
+                    indices_i = np.where(file_name == self.landmarks[1])[0]
+                    if len(indices_i) == 0:
+                        continue
+                    indices.extend([i] * len(indices_i))
+                    indices_ldm.extend(indices_i.tolist())
+                landmarks = self.landmarks[0][indices_ldm]
+            else:
+                batch, _, paddings = as_batch(images, self.resize_size)
+                images_dev = torch.from_numpy(batch).to(self.device)
+                lm_np, indices = self.det_model.predict(images_dev)
+                landmarks = lm_np - paddings[indices][:, None, [2, 0]].astype(np.float32) if len(indices) else lm_np
+
+            if landmarks is not None and len(landmarks) == 0:
+                return
+            if landmarks is not None and landmarks.shape[1] != self.num_std_landmarks:
+                slices = get_ldm_slices(self.num_std_landmarks, landmarks.shape[1])
+                landmarks = np.stack([landmarks[:, s].mean(1) for s in slices], 1)
+
+            if self.enh_model is not None:
+                if images_dev is not None:
+                    images_dev = self.enh_model.predict(images_dev, landmarks, indices)
+                else:
+                    images = [self.enh_model.predict(torch.from_numpy(im).to(self.device)[None], None, None)[0]
+                              .cpu().numpy() for im in images]
+
+            groups = (None, None)
+            if landmarks is not None:
+                if images_dev is not None:
+                    crops_dev, ok = self._crop_align_device(
+                        images_dev, paddings, list(indices),
+                        torch.from_numpy(np.ascontiguousarray(landmarks, dtype=np.float32)).to(self.device))
+                    keep = ok.cpu().numpy() != 0
+                    crops_dev = crops_dev[torch.from_numpy(keep).to(self.device)]
+                    indices = [i for i, k in zip(indices, keep) if k]
+                    faces_dev, faces = crops_dev, crops_dev.cpu().numpy()
+                else:
+                    faces = self.crop_align(images, paddings, indices, landmarks)
+                    faces_dev = torch.from_numpy(faces).to(self.device) if len(faces) else None
+            else:
+                faces, faces_dev = images, None
+            if self.par_model is not None and len(faces) > 0:
+                if faces_dev is None:
+                    faces_dev = [torch.from_numpy(np.ascontiguousarray(f)).to(self.device) for f in faces]
+                groups = self.par_model.predict(faces_dev)
+        self.save_groups(faces, file_names[indices], output_dir, *groups)
+
+    def process_dir(self, input_dir: str, output_dir: str | None = None, desc: str | None = "Processing"):
+        """cropper.py:852-909: batches of file names over a thread pool sharing the models."""
+        if output_dir is None:
+            output_dir = input_dir + "_faces"
+        files, bs = os.listdir(input_dir), self.batch_size
+        file_batches = [files[i:i + bs] for i in range(0, len(files), bs)]
+        if len(file_batches) == 0:
+            return
+        worker = partial(self.process_batch, input_dir=input_dir, output_dir=output_dir)
+        with ThreadPool(self.num_processes) as pool:
+            imap = pool.imap_unordered(worker, file_batches)
+            if desc is not None:
+                try:
+                    import tqdm
+                    imap = tqdm.tqdm(imap, total=len(file_batches), desc=desc)
+                except ImportError:
+                    pass
+            list(imap)

@@ -1,0 +1,114 @@
+"""Host utilities around the hot path (mirror of the reference's ``utils.py``
+surface that ``Cropper`` needs).  Image file I/O uses Pillow: OpenCV is not a
+dependency of this build.  ``as_batch`` is host glue here (SURVEY.md §8f-1
+"NEXT"): its resampling is Pillow's, *not* OpenCV's INTER_AREA / INTER_CUBIC
+bit-for-bit — the measured hot path starts from a batch that already has
+``resize_size``.
+"""
+from __future__ import annotations
+
+import json
+import os
+import warnings
+
+import numpy as np
+
+from .align import STANDARD_LANDMARKS_5  # noqa: F401  (re-export, utils.py:13-19)
+
+
+def parse_landmarks_file(file_path: str, **kwargs):
+    """json / csv / txt landmark files -> ((N,k,2) float32, (N,) str) (utils.py:21-88)."""
+    if file_path.endswith(".json"):
+        with open(file_path, "r") as f:
+            data = json.load(f)
+        filenames = np.array(list(data.keys()))
+        landmarks = np.array(list(data.values()), dtype=np.float32)
+    else:
+        if file_path.endswith(".csv"):
+            kwargs.setdefault("delimiter", ",")
+            kwargs.setdefault("skip_header", 1)
+        filenames = np.atleast_1d(np.genfromtxt(file_path, usecols=0, dtype=str, **kwargs))
+        landmarks = np.atleast_2d(np.genfromtxt(file_path, dtype=np.float32, **kwargs))[:, 1:]
+    return landmarks.reshape(len(landmarks), -1, 2), filenames
+
+
+_SLICES_5 = {
+    5: [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)],
+    12: [(10, 11), (11, 12), (2, 3), (3, 4), (4, 5)],
+    17: [(2, 5), (7, 10), (10, 11), (13, 14), (16, 17)],
+    21: [(6, 9), (9, 12), (14, 15), (17, 18), (19, 20)],
+    29: [(4, 9), (13, 18), (19, 20), (22, 23), (27, 28)],
+    49: [(19, 25), (25, 31), (13, 14), (31, 32), (37, 38)],
+    68: [(36, 42), (42, 48), (30, 31), (48, 49), (54, 55)],
+    98: [(60, 68), (68, 76), (54, 55), (76, 77), (82, 83)],
+    106: [(66, 75), (75, 84), (54, 55), (85, 86), (91, 92)],
+}
+
+
+def get_landmark_slices_5(num_landmarks: int):
+    """utils.py:90-132."""
+    if num_landmarks not in _SLICES_5:
+        raise ValueError(f"Invalid number of landmarks: {num_landmarks}")
+    return [slice(*x) for x in _SLICES_5[num_landmarks]]
+
+
+def get_ldm_slices(num_tgt_landmarks: int, num_src_landmarks: int):
+    """utils.py:134-168."""
+    if num_tgt_landmarks != 5:
+        raise ValueError(f"The number of target (standard) landmarks is not supported {num_tgt_landmarks}")
+    return get_landmark_slices_5(num_src_landmarks)
+
+
+def read_images(file_names, input_dir):
+    """-> (list of RGB uint8 HWC arrays, ndarray of surviving file names); unreadable
+    files warn and are skipped (utils.py:228-271)."""
+    from PIL import Image
+    indices, images = [], []
+    for i, file_name in enumerate(file_names):
+        path = os.path.join(input_dir, file_name)
+        try:
+            with Image.open(path) as im:
+                image = np.asarray(im.convert("RGB"), dtype=np.uint8)
+        except Exception:
+            warnings.warn(f"Could not read the image {path}")
+            continue
+        images.append(image)
+        indices.append(i)
+    return images, np.array(file_names)[indices]
+
+
+def as_batch(images, size=512, padding_mode: str = "constant"):
+    """Aspect-preserving resize + centred padding to a common size (utils.py:273-342).
+    Returns (batch (N,H,W,3) uint8, unscales (N,), paddings (N,4) int64 [t,b,l,r])."""
+    from PIL import Image
+    size = (size, size) if isinstance(size, int) else tuple(size)
+    batch, unscales, paddings = [], [], []
+    for image in images:
+        h, w = image.shape[:2]
+        m = max(h, w)
+        resample = Image.BOX if m > max(size) else Image.BICUBIC
+        ratio_w, ratio_h = size[0] / w, size[1] / h
+        if ratio_w < ratio_h:
+            unscale = ratio_w
+            ww, hh = size[0], int(h * ratio_w)
+            padding = [(size[1] - hh) // 2, (size[1] - hh + 1) // 2, 0, 0]
+        else:
+            unscale = ratio_h
+            ww, hh = int(w * ratio_h), size[1]
+            padding = [0, 0, (size[0] - ww) // 2, (size[0] - ww + 1) // 2]
+        if (ww, hh) != (w, h):
+            image = np.asarray(Image.fromarray(image).resize((max(ww, 1), max(hh, 1)), resample), dtype=np.uint8)
+        t, b, l, r = padding
+        mode = {"constant": "constant", "replicate": "edge", "reflect": "symmetric", "wrap": "wrap",
+                "reflect_101": "reflect"}.get(padding_mode.lower(), "constant")
+        image = np.pad(image, ((t, b), (l, r), (0, 0)), mode=mode)
+        batch.append(image)
+        unscales.append(np.array(unscale))
+        paddings.append(np.array(padding))
+    return np.stack(batch), np.stack(unscales), np.stack(paddings)
+
+
+def write_image(path: str, image: np.ndarray):
+    """RGB (or single-channel mask) uint8 array -> file; format from the extension."""
+    from PIL import Image
+    Image.fromarray(image).save(path)

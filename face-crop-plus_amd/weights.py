@@ -186,7 +186,7 @@ def generate_state_dict(model: str, seed: int = 0, as_torch: bool = True):
         out[name] = a
     if as_torch:
         import torch
-        out = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in out.items()}
+        out = {k: (torch.from_numpy(np.ascontiguousarray(v)) if v.ndim else torch.tensor(int(v))) for k, v in out.items()}
     return out
 
 
@@ -222,6 +222,8 @@ def load_state_dict(model: str, source=None, seed: int = 0):
     for k, shp in want.items():
         if k not in sd:
             raise KeyError(f"{model}: missing key {k}")
+        if k.endswith("num_batches_tracked"):
+            continue
         if tuple(sd[k].shape) != shp:
             raise ValueError(f"{model}: {k} has shape {tuple(sd[k].shape)}, expected {shp}")
     return sd
