@@ -45,6 +45,13 @@ SIGNATURES = {
     "fcp_retina_nms_select": [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
     "fcp_retina_gather_faces": [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P],
     "fcp_estimate_transform": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "fcp_bise_preprocess_u8": [_P, _I, _I, _I, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P],
+    "fcp_avgpool_nhwc_f32": [_P, _I, _I, _I, _I, _P, _P],
+    "fcp_fc_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "fcp_scale_add_nhwc_f32": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
+    "fcp_parse_tail": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "fcp_label_mask_u8": [_P, _L, C.c_uint32, _P, _P],
+    "fcp_bicubic_down4_u8": [_P, _I, _I, _I, _P, _P],
     "fcp_warp_affine_u8": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
 }
 EXPORTS = ["fcp_abi_version", "fcp_last_error", "fcp_retina_nms_workspace_bytes"] + list(SIGNATURES)

@@ -1,0 +1,117 @@
+"""RRDBNet (BSRGAN x4) enhancer on MI355X (mirror of the reference's
+``models/rrdb.py`` interface: ``RRDBNet(min_face_factor).load(device)``,
+``.predict(images, landmarks, indices)`` enhancing in place the images whose
+mean face-area factor is <= ``min_face_factor``).
+
+All 351 convolutions run on the fp32-MFMA engine with bias / LeakyReLU(0.2) /
+``x5*0.2 + x`` / ``out*0.2 + x`` fused into the epilogues.  A dense block's
+``torch.cat((x, x1, ..))`` is one 192-channel NHWC buffer: each conv reads the
+leading channels and appends 32 more, so nothing is ever copied; the two nearest
+x2 upsamples are folded into the following conv's operand fetch.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import engine as E
+from .weights import load_state_dict
+
+
+class RRDBNet:
+    WEIGHTS_FILENAME = "bsrgan_x4_enhancer.pth"
+    NUM_BLOCKS = 23
+
+    def __init__(self, min_face_factor: float = 0.001):
+        self.min_face_factor = min_face_factor
+        self.device = None
+        self._p = None
+
+    def load(self, device="cuda:0", weights=None):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("face_crop_plus_amd runs on an AMD GPU only; there is no CPU fallback")
+        N.lib()
+        self.device = device
+        sd = load_state_dict("rrdb", weights)
+        with torch.cuda.device(device):
+            pc = lambda k: E.pack_conv(sd[k + ".weight"], sd[k + ".bias"], None, 1, 1, device)
+            p = {k: pc(k) for k in ("conv_first", "trunk_conv", "upconv1", "upconv2", "HRconv", "conv_last")}
+            p["trunk"] = [[[pc(f"RRDB_trunk.{t}.RDB{r}.conv{c}") for c in range(1, 6)] for r in (1, 2, 3)]
+                          for t in range(self.NUM_BLOCKS)]
+            self._p = p
+        return self
+
+    def forward(self, x4: E.Act) -> E.Act:
+        """NHWC4 image in [0,1] (n,h,w,4) -> (n,4h,4w,4) with the RGB output in channels 0..2."""
+        p = self._p
+        n, h, w, dev = x4.n, x4.h, x4.w, x4.buf.device
+        bufs = [E.Act.empty(n, h, w, 192, dev) for _ in range(3)]     # one dense-block concat buffer per RDB
+        fea0 = E.conv(p["conv_first"], x4)                             # kept for the trunk residual
+        E.conv(p["conv_first"], x4, bufs[0].slice(0, 64))              # and as x of the first RDB
+        for t, rrdb in enumerate(p["trunk"]):
+            for r, convs in enumerate(rrdb):
+                b = bufs[r]
+                for c in range(4):                                     # x_{c+1} = lrelu(conv(cat(x..x_c)))
+                    E.conv(convs[c], b.slice(0, 64 + 32 * c), b.slice(64 + 32 * c, 32), act_slope=0.2)
+                nxt = bufs[(r + 1) % 3]
+                if r < 2:                                              # x5*0.2 + x -> next RDB's x
+                    E.conv(convs[4], b, nxt.slice(0, 64), alpha=0.2, res1=b.slice(0, 64), res1_pre=False)
+                else:                                                  # (x5*0.2 + x)*0.2 + x_rrdb
+                    E.conv(convs[4], b, nxt.slice(0, 64), alpha=0.2, res1=b.slice(0, 64), res1_pre=False,
+                           res2=bufs[0].slice(0, 64), alpha2=0.2)
+        fea = E.conv(p["trunk_conv"], bufs[0].slice(0, 64), res1=fea0, res1_pre=False)
+        del bufs
+        fea = E.conv(p["upconv1"], fea, act_slope=0.2, in_up2=True)
+        fea = E.conv(p["upconv2"], fea, act_slope=0.2, in_up2=True)
+        fea = E.conv(p["HRconv"], fea, act_slope=0.2)
+        out = E.Act.empty(n, 4 * h, 4 * w, 4, dev)
+        E.conv(p["conv_last"], fea, out.slice(0, 3))
+        return out
+
+    def enhance_u8(self, images_u8: torch.Tensor, which) -> torch.Tensor:
+        """Enhance in place the listed images of a (n,h,w,3) uint8 device batch."""
+        n, h, w, _ = images_u8.shape
+        for i in which:
+            x4 = E.u8_to_nhwc4(images_u8[i:i + 1], sub=(0.0, 0.0, 0.0), div=255.0)   # `.div(255)`, rrdb.py:142
+            y = self.forward(x4)
+            N.check(N.lib().fcp_bicubic_down4_u8(y.ptr(), h, w, y.ld, N.ptr(images_u8, i * h * w * 3),
+                                                 N.stream_ptr()), "fcp_bicubic_down4_u8")
+        return images_u8
+
+    def gate(self, n_images, h, w, landmarks, indices):
+        """rrdb.py:124-140: enhance iff mean((x4-x0)*(y4-y0)/(H*W)) <= min_face_factor."""
+        out = []
+        for i in range(n_images):
+            if landmarks is None or indices is None:
+                out.append(i)
+                continue
+            lm = landmarks[[idx == i for idx in indices]]
+            if len(lm) == 0:
+                continue
+            wv, hv = (lm[:, 4] - lm[:, 0]).T
+            if (wv * hv / (h * w)).mean() <= self.min_face_factor:
+                out.append(i)
+        return out
+
+    @torch.no_grad()
+    def predict(self, images, landmarks: np.ndarray | None, indices: list | None):
+        """Reference signature (rrdb.py:84-146).  ``images``: (N,H,W,3) uint8 device batch (fast
+        path, modified in place and returned) or (N,3,H,W) float 0..255 (returned as float)."""
+        with torch.cuda.device(self.device):
+            if isinstance(images, torch.Tensor) and images.dtype == torch.uint8:
+                images = images.to(self.device)
+                return self.enhance_u8(images, self.gate(len(images), images.shape[1], images.shape[2],
+                                                         landmarks, indices))
+            as_list = isinstance(images, list)
+            outs = []
+            h0, w0 = images[0].shape[1], images[0].shape[2]
+            todo = set(self.gate(len(images), h0, w0, landmarks, indices))
+            for i in range(len(images)):
+                img = images[i]
+                if i in todo:
+                    u8 = img.permute(1, 2, 0).to(self.device).to(torch.uint8).contiguous()[None]
+                    img = self.enhance_u8(u8, [0])[0].permute(2, 0, 1).float().to(img.device)
+                outs.append(img)
+            return outs if as_list else torch.stack(outs)

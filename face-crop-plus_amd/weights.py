@@ -156,11 +156,15 @@ def generate_state_dict(model: str, seed: int = 0, as_torch: bool = True):
                 gain = 1.0
             if name.endswith("conv1x1.weight"):
                 gain = 0.01   # head inputs have std ~10: keep regressions O(1)
-            if "conv_out.conv_out" in name or name.startswith("conv_last"):
+            if "conv_out.conv_out" in name:
                 gain = 1.0
+            if name.startswith("conv_last"):
+                gain = 0.0003  # keeps the x4 output inside (0,1) so the clamp/round tail is exercised
             a = rng.standard_normal(shape, dtype=np.float32) * np.float32(np.sqrt(gain / fan_in))
         elif kind == CONV_B:
             a = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.05)
+            if name == "conv_last.bias":
+                a = a + np.float32(0.5)
             if model == "retinaface" and name.startswith("ClassHead"):
                 # channels are (anchor0: bg, face, anchor1: bg, face)
                 a = a.copy()

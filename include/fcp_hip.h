@@ -171,6 +171,55 @@ int fcp_warp_affine_u8(const uint8_t* images, int n, int h, int w,
                        const int32_t* paddings, int f, int out_h, int out_w, int border,
                        uint8_t* out, fcp_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * BiSeNet face parser glue (models/bise.py, _layers.py:206-368).
+ * ------------------------------------------------------------------------ */
+
+/* bise.py:387-393: faces (f,h,w,3) uint8 RGB -> `/255`, bilinear to (out_h,out_w)
+ * with align_corners=False, `(x-mean)/std` -> fp32 NHWC4 (f,out_h,out_w,4).
+ * mean_host/std_host: 3 floats each on the host. */
+int fcp_bise_preprocess_u8(const uint8_t* faces, int f, int h, int w, float* out,
+                           int out_h, int out_w, const float* mean_host,
+                           const float* std_host, fcp_stream_t stream);
+
+/* F.avg_pool2d(x, x.size()[2:]) on an NHWC slice (_layers.py:307,:332,:360):
+ * in (n,hw,ld) channels [0,c) -> out (n,c). */
+int fcp_avgpool_nhwc_f32(const float* in, int n, int hw, int c, int ld, float* out,
+                         fcp_stream_t stream);
+
+/* 1x1 conv on a 1x1 map (+ folded BatchNorm) (+ ReLU / sigmoid): ARM conv_atten,
+ * ContextPath conv_avg, FFM conv1/conv2 (_layers.py:308-310,:333,:361-364).
+ * out[n][co] = act(scale[co] * dot(w[co,:], in[n,:]) + shift[co]);
+ * scale/shift may be NULL; act: 0 none, 1 relu, 2 sigmoid. */
+int fcp_fc_f32(const float* in, const float* w, const float* scale, const float* shift,
+               int n, int cin, int cout, int act, float* out, fcp_stream_t stream);
+
+/* out = x * scale_nc[n,c] (+ add_nc[n,c]) (+ add_t[n,h,w,c]): torch.mul(feat, atten)
+ * followed by `+ avg_up` / `+ feat32_up` / `+ feat` (_layers.py:311,:337,:342,:365-366). */
+int fcp_scale_add_nhwc_f32(const float* x, int x_ld, const float* scale_nc,
+                           const float* add_nc, const float* add_t, int add_t_ld,
+                           int n, int hw, int c, float* out, int out_ld, fcp_stream_t stream);
+
+/* Parse tail (bise.py:212 + :394): logits (f,lh,lw,ld) at 1/8 resolution ->
+ * bilinear align_corners=True to (mid_h,mid_w) -> nearest to (out_h,out_w) ->
+ * argmax (first maximum) -> labels (f,out_h,out_w) uint8.  counts (f,ncls) int32
+ * = per-face class histogram (bise.py:253-254), may be NULL. */
+int fcp_parse_tail(const float* logits, int f, int lh, int lw, int ld, int ncls,
+                   int mid_h, int mid_w, int out_h, int out_w, uint8_t* labels,
+                   int32_t* counts, fcp_stream_t stream);
+
+/* mask = 255 where bit `label` of class_bits is set, else 0 (bise.py:314-319). */
+int fcp_label_mask_u8(const uint8_t* labels, int64_t total, uint32_t class_bits,
+                      uint8_t* mask, fcp_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * RRDB enhancer tail (rrdb.py:143-144): x4 (4h,4w,ld>=3) fp32 in [0,1] ->
+ * bicubic x0.25 (align_corners=False, A=-0.75: taps (-3,19,19,-3)/32) ->
+ * clamp(0,1)*255 -> round-half-even -> uint8 RGB (h,w,3).
+ * ------------------------------------------------------------------------ */
+int fcp_bicubic_down4_u8(const float* x4, int h, int w, int ld, uint8_t* out_rgb,
+                         fcp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,12 +129,72 @@ def golden_retina_full(ref):
     np.savez_compressed(os.path.join(HERE, "retina_full.npz"), **out)
 
 
+def golden_bisenet(ref):
+    sd = weights.generate_state_dict("bisenet")
+    attr = {"hair_and_hat": [17, 14], "no_cloth": [-16], "hair_only": [17, -14], "neck": [12]}
+    mask = {"hair": [17], "neck_or_hat": [12, 14], "eyes": [4, 5]}
+    m = ref.BiSeNet(attr, mask, 2)
+    m.load_state_dict(sd)
+    m.eval()
+    g = torch.Generator().manual_seed(31)
+    faces = torch.randint(0, 256, (3, 64, 64, 3), generator=g, dtype=torch.uint8)
+    faces[1, :, :32] //= 4            # darker half: a little variety between faces
+    x = faces.permute(0, 3, 1, 2).float()
+    out = dict(faces=faces.numpy(), sd_digest=np.array(sd_digest(sd)))
+    with torch.no_grad():
+        import torch.nn.functional as F
+        mean = torch.tensor(m.mean).view(1, 3, 1, 1)
+        std = torch.tensor(m.std).view(1, 3, 1, 1)
+        xin = (F.interpolate(x.div(255), (512, 512), mode="bilinear") - mean) / std
+        o = F.interpolate(m(xin), (64, 64), mode="nearest")
+        t2 = torch.topk(o, 2, dim=1).values
+        out["top2_gap"] = (t2[:, 0] - t2[:, 1]).numpy()      # margin of every label decision
+        out["labels"] = o.argmax(1).numpy().astype(np.uint8)
+        ag, mg = m.predict(x)
+    out["attr_keys"] = np.array(sorted(ag.keys()))
+    for k, v in ag.items():
+        out[f"attr_{k}"] = np.array(v, np.int64)
+    out["mask_keys"] = np.array(sorted(mg.keys()))
+    for k, (idx, masks) in mg.items():
+        out[f"mask_{k}_idx"] = np.array(idx, np.int64)
+        out[f"mask_{k}"] = masks
+    np.savez_compressed(os.path.join(HERE, "bisenet.npz"), **out)
+    print("bisenet groups:", {k: v for k, v in ag.items()}, {k: v[0] for k, v in mg.items()},
+          np.bincount(out["labels"].ravel(), minlength=19))
+
+
+def golden_rrdb(ref):
+    sd = weights.generate_state_dict("rrdb")
+    m = ref.RRDBNet(0.02)
+    m.load_state_dict(sd)
+    m.eval()
+    g = torch.Generator().manual_seed(41)
+    img = torch.randint(0, 256, (3, 20, 24, 3), generator=g, dtype=torch.uint8)
+    x = img.permute(0, 3, 1, 2).float()
+    # image 0: small face (enhanced), image 1: large face (kept), image 2: no landmarks (kept)
+    lm = np.zeros((2, 5, 2), np.float32)
+    lm[0, 0] = [5, 5]; lm[0, 4] = [7, 8]
+    lm[1, 0] = [2, 2]; lm[1, 4] = [20, 18]
+    idx = [0, 1]
+    out = dict(image=img.numpy(), landmarks=lm, indices=np.array(idx), sd_digest=np.array(sd_digest(sd)))
+    with torch.no_grad():
+        out["x4_image0"] = m(x[:1].div(255)).numpy()
+        res = m.predict(x.clone(), lm, idx)
+        out["pred"] = res.numpy()
+        res_all = m.predict(x.clone(), None, None)
+        out["pred_all"] = res_all.numpy()
+    np.savez_compressed(os.path.join(HERE, "rrdb.npz"), **out)
+    print("rrdb changed images:", [bool((res[i] != x[i]).any()) for i in range(3)])
+
+
 def main():
     ref = load_reference_models()
     torch.manual_seed(0)
     golden_priors(ref)
     golden_postprocess(ref)
     golden_retina_full(ref)
+    golden_bisenet(ref)
+    golden_rrdb(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
