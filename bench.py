@@ -48,23 +48,6 @@ def parse():
     return ap.parse_args()
 
 
-def broadcast_state_dict(sd, rank, world, dev):
-    """Rank 0's weights -> every rank, one flat fp32 RCCL broadcast over xGMI."""
-    import torch.distributed as dist
-    keys = sorted(k for k in sd if not k.endswith("num_batches_tracked"))
-    flat = torch.cat([sd[k].reshape(-1).float() for k in keys]).to(dev)
-    if rank != 0:
-        flat.zero_()
-    dist.broadcast(flat, src=0)
-    out, off = dict(sd), 0
-    flat = flat.cpu()
-    for k in keys:
-        n = sd[k].numel()
-        out[k] = flat[off:off + n].reshape(sd[k].shape).clone()
-        off += n
-    return out
-
-
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -87,7 +70,8 @@ def main():
 
     sd = weights.generate_state_dict("retinaface")
     if world > 1:
-        sd = broadcast_state_dict(sd, rank, world, dev)
+        from face_crop_plus_amd.dist import broadcast_state_dict
+        sd = broadcast_state_dict(sd, dev)
     det = RetinaFace(args.strategy, 0.6).load(dev, sd)
     from face_crop_plus_amd.cropper import landmarks_target
     tgt = torch.from_numpy(landmarks_target((args.out_size, args.out_size), 0.65)).to(dev)

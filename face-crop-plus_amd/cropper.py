@@ -252,7 +252,10 @@ class Cropper:
         if output_dir is None:
             output_dir = input_dir + "_faces"
         files, bs = os.listdir(input_dir), self.batch_size
+        files = sorted(files)          # deterministic batches, so ranks agree on the partition
         file_batches = [files[i:i + bs] for i in range(0, len(files), bs)]
+        from .dist import shard
+        file_batches = shard(file_batches)   # rank r of R takes batches r, r+R, ... (no-op single-process)
         if len(file_batches) == 0:
             return
         worker = partial(self.process_batch, input_dir=input_dir, output_dir=output_dir)

@@ -1,0 +1,93 @@
+"""End-to-end Cropper.process_dir on generated image files (config 0: plumbing on the GPU path)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import retinaface_ref as R, align_ref as A
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def image_dir(tmp_path_factory):
+    from PIL import Image
+    d = tmp_path_factory.mktemp("imgs")
+    rng = np.random.default_rng(7)
+    for i, (h, w) in enumerate([(160, 160), (160, 160), (120, 160), (200, 100), (160, 160)]):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(d / f"{i:06d}.png")
+    (d / "broken.png").write_bytes(b"nope")
+    return str(d)
+
+
+def test_process_dir_matches_oracle(image_dir, tmp_path, device):
+    from PIL import Image
+    from face_crop_plus_amd import Cropper, weights, utils
+    sd = weights.generate_state_dict("retinaface")
+    out = tmp_path / "faces"
+    c = Cropper(output_size=64, resize_size=160, strategy="largest", det_threshold=0.6, batch_size=3,
+                output_format="png", device="cuda:0", weights={"retinaface": sd})
+    with pytest.warns(UserWarning):
+        c.process_dir(image_dir, str(out), desc=None)
+    written = sorted(os.listdir(out))
+    assert written and all(f.endswith(".png") for f in written)
+    # oracle: same batch building, CPU detector + OpenCV-restated crop
+    names = sorted(f for f in os.listdir(image_dir) if f != "broken.png")
+    imgs, _ = utils.read_images(names, image_dir)
+    batch, _, pads = utils.as_batch(imgs, (160, 160))
+    lm, idx = R.predict(torch.from_numpy(batch).permute(0, 3, 1, 2).float(), sd, "largest", 0.6)
+    lm = lm - pads[idx][:, None, [2, 0]]
+    crops = A.crop_align(batch, pads, idx, lm, A.landmarks_target((64, 64), 0.65), (64, 64), "constant")
+    assert written == [names[i] for i in idx]
+    worst = 0
+    for k, i in enumerate(idx):
+        got = np.asarray(Image.open(out / names[i]).convert("RGB"))
+        worst = max(worst, int(np.abs(got.astype(int) - crops[k].astype(int)).max()))
+        # landmarks agree to ~1e-4 px, so at most isolated fixed-point weight flips may differ
+        assert (got != crops[k]).mean() < 0.01
+    print("worst crop byte difference vs oracle:", worst)
+
+
+def test_process_dir_all_strategy_groups_and_masks(image_dir, tmp_path, device):
+    from face_crop_plus_amd import Cropper
+    out = tmp_path / "grouped"
+    c = Cropper(output_size=64, resize_size=160, strategy="all", det_threshold=0.6, batch_size=4,
+                attr_groups={"hair": [17], "no_hat": [-14]}, mask_groups={"hair": [17]},
+                device="cuda:0", weights={k: "generated" for k in ("retinaface", "bisenet")})
+    with pytest.warns(UserWarning):
+        c.process_dir(image_dir, str(out), desc=None)
+    tree = {os.path.relpath(os.path.join(dp, f), out) for dp, _, fs in os.walk(out) for f in fs}
+    assert tree, "no outputs written"
+    assert all(p.split(os.sep)[0] in ("hair", "no_hat") for p in tree)
+    assert any(p.split(os.sep)[1] == "hair_mask" for p in tree)          # attr / mask cross product (cropper.py:731-746)
+    assert all(os.path.splitext(p)[0].rsplit("_", 1)[1].isdigit() for p in tree)   # "_N" suffix for strategy "all"
+
+
+def test_given_landmarks_and_enhancement(image_dir, tmp_path, device):
+    """Pre-computed landmark path (no detector) + RRDB enhancement of every image (landmarks=None rule)."""
+    from face_crop_plus_amd import Cropper
+    tgt = A.landmarks_target((48, 48), 0.65)
+    lms = np.stack([tgt * 1.5 + 10, tgt * 1.2 + 20]).astype(np.float32)
+    names = np.array(["000000.png", "000003.png"])
+    out = tmp_path / "given"
+    c = Cropper(output_size=48, landmarks=(lms, names), det_threshold=None, padding="reflect", device="cuda:0")
+    c.process_dir(image_dir, str(out), desc=None)
+    assert sorted(os.listdir(out)) == ["000000.png", "000003.png"]
+    from PIL import Image
+    src = np.asarray(Image.open(os.path.join(image_dir, "000003.png")).convert("RGB"))
+    exp = A.warp_affine(src, A.estimate_transform(lms[1], tgt), (48, 48), A.BORDER["reflect"])
+    assert np.array_equal(np.asarray(Image.open(out / "000003.png").convert("RGB")), exp)
+
+
+def test_crop_align_numpy_signature(device):
+    from face_crop_plus_amd import Cropper
+    c = Cropper(output_size=32, det_threshold=None, device="cuda:0")
+    rng = np.random.default_rng(2)
+    imgs = rng.integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
+    lm = np.stack([c.landmarks_target * 1.5 + 4, np.ones((5, 2), np.float32), c.landmarks_target + 9]).astype(np.float32)
+    out = c.crop_align(imgs, np.array([[0, 0, 0, 0], [2, 2, 0, 0]]), [0, 1, 1], lm)
+    assert out.shape == (2, 32, 32, 3) and out.dtype == np.uint8          # degenerate face dropped
+    ragged = c.crop_align([imgs[0], imgs[1][:50]], None, [0, 1], lm[[0, 2]])
+    assert ragged.shape == (2, 32, 32, 3)
+    assert np.array_equal(ragged[0], out[0])
