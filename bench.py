@@ -124,9 +124,19 @@ def main():
         launches = len(E.ConvStats.timing)
         E.ConvStats.timing = None
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_conv.json")) \
+            if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if prof and args.batch == 64 and args.size == 640:
+            # HBM bytes per conv launch from the committed rocprofv3 --pmc passes of this same command
+            with open(os.path.join(ROOT, "profiles", prof[-1])) as f:
+                traffic = round(json.load(f)["hbm_bytes_per_launch"])
+            traffic_src = "profiles/" + prof[-1]
         roofline = {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)",
                     "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per conv launch (PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+                    "traffic_source": traffic_src,
                     "launches_per_step": launches, "algorithmic_gflop_per_step": round(conv_flops / 1e9, 2),
                     "avg_launch_ms": round(conv_ms / launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
 

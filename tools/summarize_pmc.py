@@ -1,0 +1,42 @@
+"""Reduce rocprofv3 --pmc CSVs (separate FETCH_SIZE / WRITE_SIZE / SQ passes of the same bench
+command) to a per-launch summary of the conv kernel.
+
+    python tools/summarize_pmc.py gpurun_out/pmc_r1 profiles/r01_pmc_conv.json
+
+Units / corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are KiB;
+on gfx950 FETCH_SIZE counts 128-byte requests as 64 B for wide coalesced reads, so reads are doubled
+(checked here on the stem launch, whose input size is known exactly)."""
+import collections, csv, json, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+LAUNCHES = 70
+
+
+def load(path):
+    d = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        d.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"]})[r["Counter_Name"]] = float(r["Counter_Value"])
+    return [v for v in d.values() if "conv_igemm" in v["name"]][-LAUNCHES:]
+
+
+f, w, s = (load(f"{src}/{k}/b_counter_collection.csv") for k in ("fetch", "write", "sq"))
+fetch_kib = sum(v["FETCH_SIZE"] for v in f)
+write_kib = sum(v["WRITE_SIZE"] for v in w)
+stem_expected_kib = 64 * 640 * 640 * 16 / 1024          # NHWC4 fp32 input of the batch-64 640^2 stem
+read_corr = 2.0
+mfma_busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in s)
+gui = sum(v["GRBM_GUI_ACTIVE"] for v in s)               # summed over the 8 XCDs
+out = {
+    "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline (batch 64, 640x640), last step's 70 conv launches",
+    "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
+    "fetch_calibration": {"stem_reported_kib": f[0]["FETCH_SIZE"], "stem_expected_kib": stem_expected_kib,
+                          "ratio": f[0]["FETCH_SIZE"] / stem_expected_kib, "correction_applied": read_corr},
+    "hbm_bytes_per_step": (fetch_kib * read_corr + write_kib) * 1024,
+    "hbm_bytes_per_launch": (fetch_kib * read_corr + write_kib) * 1024 / LAUNCHES,
+    "mfma_busy_cycles": mfma_busy, "grbm_gui_active_sum_8xcd": gui,
+    "mfma_util": mfma_busy / (gui / 8 * 1024),
+    "note": "SQ_VALU_MFMA_BUSY_CYCLES = 64 cycles per v_mfma_f32_32x32x2_f32 summed over 1024 SIMDs (includes "
+            "zero-padded cout / stem-K work); GRBM_GUI_ACTIVE is summed over the 8 XCDs",
+}
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1))
