@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--out-size", type=int, default=256)
     ap.add_argument("--strategy", default="largest")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the batch is split over")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
 
@@ -80,19 +82,46 @@ def main():
     images = torch.randint(0, 256, (args.batch, args.size, args.size, 3), generator=g, dtype=torch.uint8).to(dev)
     face_total = torch.zeros((), dtype=torch.int64, device=dev)
 
-    def step(count=True):
-        res = det.detect(images, max_faces=args.batch if args.strategy != "all" else None)
-        crops, ok, _ = align.crop_align(images, res["img_idx"], res["landmarks"], tgt,
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [None]
+    chunks = list(torch.chunk(images, len(streams)))
+
+    def step_chunk(imgs, count):
+        res = det.detect(imgs, max_faces=imgs.shape[0] if args.strategy != "all" else None)
+        crops, ok, _ = align.crop_align(imgs, res["img_idx"], res["landmarks"], tgt,
                                         (args.out_size, args.out_size), 0)
         if count:
             nf = torch.clamp(res["face_offset"][-1].to(torch.int64), max=res["max_faces"])
             valid = (torch.arange(res["max_faces"], device=dev) < nf) & (ok != 0)
-            face_total.add_(valid.sum())
-        return crops
+            return crops, valid.sum()
+        return crops, None
 
+    def step(count=True):
+        """One pass of the hot path over the batch.  With --streams S the batch is split into S
+        independent sub-batches on S HIP streams, so one sub-batch's tail wave of workgroups
+        overlaps the next one's head (the path has no cross-image dependency)."""
+        if streams[0] is None:
+            crops, nv = step_chunk(images, count)
+            if count:
+                face_total.add_(nv)
+            return crops
+        cur = torch.cuda.current_stream()
+        outs = []
+        for st, imgs in zip(streams, chunks):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(step_chunk(imgs, count))
+        for st in streams:
+            cur.wait_stream(st)
+        if count:
+            for _, nv in outs:
+                face_total.add_(nv)
+        return [c for c, _ in outs]
+
+    E.Autotune.enabled = not args.no_autotune      # tile choice per conv shape, decided during warm-up
     for _ in range(args.warmup):
         step(True)                       # identical to the timed step (incl. lazy module loads)
     torch.cuda.synchronize()
+    E.Autotune.enabled = False
     face_total.zero_()
     if dist is not None:
         dist.barrier()

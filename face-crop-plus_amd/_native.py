@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_f32p = C.c_void_p
 _lib = None
@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
     """Mirror of ``fcp_conv_desc``."""
     _fields_ = [
         ("in_", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
-        ("res1", C.c_void_p), ("res2", C.c_void_p),
+        ("res1", C.c_void_p), ("res2", C.c_void_p), ("wscale", C.c_void_p),
         ("n", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
         ("cin", C.c_int32), ("in_ld", C.c_int32), ("in_up2", C.c_int32),
         ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
         ("tile_n", C.c_int32), ("cin4", C.c_int32),
         ("act_slope", C.c_float), ("alpha", C.c_float), ("alpha2", C.c_float),
         ("res1_pre", C.c_int32), ("res1_ld", C.c_int32), ("res1_h", C.c_int32),
-        ("res1_w", C.c_int32), ("res2_ld", C.c_int32),
+        ("res1_w", C.c_int32), ("res2_ld", C.c_int32), ("precision", C.c_int32),
     ]
 
 

@@ -39,14 +39,14 @@ class BiSeNet:
         self.device = None
         self._p = None
 
-    def load(self, device="cuda:0", weights=None):
+    def load(self, device="cuda:0", weights=None, precision=None):
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("face_crop_plus_amd runs on an AMD GPU only; there is no CPU fallback")
         N.lib()
         self.device = device
         sd = load_state_dict("bisenet", weights)
-        with torch.cuda.device(device):
+        with torch.cuda.device(device), E.default_precision(precision):
             self._p = self._pack(sd, device)
         return self
 

@@ -47,6 +47,7 @@ class Cropper:
         num_processes: int = 1,
         device: str | torch.device = "cuda:0",
         weights: dict | None = None,
+        precision: str | None = None,
     ):
         """Arguments as in the reference (cropper.py:139-156).  ``device`` must be a GPU
         (``"cuda:N"``); ``weights`` optionally maps "retinaface"/"rrdb"/"bisenet" to a
@@ -68,6 +69,7 @@ class Cropper:
         self.num_processes = num_processes
         self.device = device
         self.weights = weights or {}
+        self.precision = precision   # "f16x3" (default) | "f32": arithmetic of the conv engine
         self.num_std_landmarks = 5
 
         if isinstance(self.output_size, int):
@@ -100,15 +102,15 @@ class Cropper:
         if self.det_threshold is not None and self.landmarks is None:
             from .retinaface import RetinaFace
             self.det_model = RetinaFace(self.strategy, self.det_threshold)
-            self.det_model.load(self.device, self.weights.get("retinaface"))
+            self.det_model.load(self.device, self.weights.get("retinaface"), self.precision)
         if self.enh_threshold is not None:
             from .rrdb import RRDBNet
             self.enh_model = RRDBNet(self.enh_threshold)
-            self.enh_model.load(self.device, self.weights.get("rrdb"))
+            self.enh_model.load(self.device, self.weights.get("rrdb"), self.precision)
         if self.attr_groups is not None or self.mask_groups is not None:
             from .bise import BiSeNet
             self.par_model = BiSeNet(self.attr_groups, self.mask_groups, self.batch_size)
-            self.par_model.load(self.device, self.weights.get("bisenet"))
+            self.par_model.load(self.device, self.weights.get("bisenet"), self.precision)
 
     def _init_landmarks_target(self):
         if self.num_std_landmarks != 5:

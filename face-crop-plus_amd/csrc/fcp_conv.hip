@@ -9,44 +9,24 @@
 // v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-for-bit an fmaf chain, so
 // results differ from the reference's ATen conv only by summation order.
 //
-// LDS image: [row][36] floats (32 + 4 pad -> 144-byte rows).  Fragments are
-// fetched with ds_read_b128: lane l reads 4 consecutive k of row (l & 31) at
-// k-chunk 2p + (l >> 5); element e of that vector feeds MFMA #e of the group,
-// i.e. the hardware's "k index = lane >> 5" is mapped to physical k = 8p+e /
-// 8p+4+e identically for A and B (any bijection of k is a valid contraction
-// order).  9*r mod 16 is a bijection on every 16-lane service group of
-// ds_read_b128, so the reads are bank-conflict free.
-#include "fcp_common.h"
-#include "fcp_hip.h"
+// LDS image: [row][32] floats, the eight 16-byte chunks of a row XOR-swizzled by
+// (row >> 1) & 7.  Fragments are fetched with ds_read_b128: lane l reads 4
+// consecutive k of row (l & 31) at k-chunk 2p + (l >> 5); element e of that
+// vector feeds MFMA #e of the group, i.e. the hardware's "k index = lane >> 5"
+// is mapped to physical k = 8p+e / 8p+4+e identically for A and B (any
+// bijection of k is a valid contraction order).  With the swizzle every 16-lane
+// service group of ds_read_b128 touches 16 distinct bank slots (conflict free)
+// and, unpadded, three 128x64 workgroups fit one CU's 160 KiB of LDS.
+#include "fcp_conv_common.h"
 
 #include <cstdlib>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace fcp_conv;
 
 namespace {
 
-constexpr int BM = 128;
-constexpr int BK = 32;
-constexpr int LDK = 36;  // floats per LDS row
+constexpr int LDK = 32;  // floats per LDS row (XOR-swizzled 16-byte chunks, no padding)
 
-struct ConvK {
-  const float* in;
-  const float* w;
-  const float* bias;
-  float* out;
-  const float* res1;
-  const float* res2;
-  int n, in_h, in_w, ph, pw, cin, in_ld, in_up2;
-  int cout, kh, kw, stride, pad, out_h, out_w, out_ld;
-  int M, ktiles, ctiles, wrow;
-  float act_slope, alpha, alpha2;
-  int res1_pre, res1_ld, res1_h, res1_w, res1_resize, res2_ld;
-  float res1_sh, res1_sw;
-  int grid_m, grid_n, vec_ok;
-  unsigned in_bytes, w_bytes;
-  int ablate;  // profiling-only knob (env FCP_CONV_ABLATE), 0 in production
-};
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -60,7 +40,7 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigne
 // compiler can interleave the fetches with the MFMA stream.  Tensors of 4 GiB or
 // more fall back to flat 64-bit addressing (BUF = false).
 template <int BN, bool CIN4, bool BUF>
-__global__ void __launch_bounds__(256) conv_igemm_f32(const ConvK p) {
+__global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) conv_igemm_f32(const ConvK p) {
   constexpr int WAVES_N = (BN == 32) ? 1 : 2;
   constexpr int WAVES_M = 4 / WAVES_N;
   constexpr int WTM = BM / WAVES_M;
@@ -91,7 +71,8 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvK p) {
   const int lrow = tid >> 3;  // 0..31
 
   // per-thread im2col row bookkeeping
-  long nbase[A_LD];
+  long nbase[A_LD];        // flat path only
+  unsigned pbase[A_LD];    // buffer path: first pixel of the row's image (32-bit)
   int hi0[A_LD], wi0[A_LD];
   const int hw = p.out_h * p.out_w;
 #pragma unroll
@@ -103,10 +84,12 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvK p) {
       const int ho = rem / p.out_w;
       const int wo = rem - ho * p.out_w;
       nbase[i] = (long)ni * p.ph * p.pw;
+      pbase[i] = (unsigned)(ni * p.ph * p.pw);
       hi0[i] = ho * p.stride - p.pad;
       wi0[i] = wo * p.stride - p.pad;
     } else {
       nbase[i] = 0;
+      pbase[i] = 0;
       hi0[i] = -(1 << 28);
       wi0[i] = 0;
     }
@@ -130,14 +113,17 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvK p) {
       int wi = wi0[i] + (CIN4 ? chunk : kw_i);
       const bool ok = (unsigned)hi < (unsigned)p.in_h && (unsigned)wi < (unsigned)p.in_w;
       if (p.in_up2) { hi >>= 1; wi >>= 1; }
-      const unsigned pix = (unsigned)nbase[i] + (unsigned)(hi * p.pw + wi);
+      const unsigned pix = pbase[i] + (unsigned)(hi * p.pw + wi);
       rowoff[i] = ok ? (pix * (unsigned)p.in_ld + (CIN4 ? 0u : (unsigned)(chunk * 4))) * 4u : 0xFFFFFFFFu;
     }
   };
 
-  f32x4 ra[A_LD], rb[B_LD];
+  // two register sets: the fetch of slice k+2 is in flight while slice k is multiplied and
+  // slice k+1 (fetched one full iteration earlier) is written to LDS — a prefetch distance of
+  // two MFMA phases, enough to cover HBM / Infinity-Cache latency of activations that miss L2.
+  f32x4 ra0[A_LD], rb0[B_LD], ra1[A_LD], rb1[B_LD];
 
-  auto load_slice = [&](int kt, int kh_i, int kw_i, int c0) {
+  auto load_slice = [&](f32x4 (&ra)[A_LD], f32x4 (&rb)[B_LD], int kt, int kh_i, int kw_i, int c0) {
     if (BUF) {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
@@ -162,9 +148,13 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvK p) {
         rb[i] = *reinterpret_cast<const f32x4*>(wbase + (long)(32 * i) * p.wrow + kt * BK);
     }
   };
-  auto store_slice = [&](int buf) {
-    float* a = As + buf * BM * LDK + lrow * LDK + chunk * 4;
-    float* b = Bs + buf * BN * LDK + lrow * LDK + chunk * 4;
+  // chunk' = chunk ^ ((row >> 1) & 7): a 16-lane ds_read_b128 service group then touches 16
+  // distinct 16-byte bank slots (rows of equal parity get distinct chunks), conflict-free
+  // without padding; rows are 128 B so three 128x64 workgroups fit one CU's 160 KiB.
+  const int schunk = chunk ^ ((lrow >> 1) & 7);
+  auto store_slice = [&](const f32x4 (&ra)[A_LD], const f32x4 (&rb)[B_LD], int buf) {
+    float* a = As + buf * BM * LDK + lrow * LDK + schunk * 4;
+    float* b = Bs + buf * BN * LDK + lrow * LDK + schunk * 4;
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) *reinterpret_cast<f32x4*>(a + 32 * i * LDK) = ra[i];
 #pragma unroll
@@ -194,30 +184,23 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvK p) {
     }
   };
 
-  if (BUF) set_tap(0, 0);
-  load_slice(0, kh_i, kw_i, c0);
-  store_slice(0);
-  __syncthreads();
+  const int aoff = (wm * WTM + (lane & 31)) * LDK;
+  const int boff = (wn * WTN + (lane & 31)) * LDK;
+  const int rsw = ((lane & 31) >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) koff[pp] = (((2 * pp + (lane >> 5)) ^ rsw)) * 4;
 
-  const int aoff = (wm * WTM + (lane & 31)) * LDK + (lane >> 5) * 4;
-  const int boff = (wn * WTN + (lane & 31)) * LDK + (lane >> 5) * 4;
-
-  for (int kt = 0; kt < p.ktiles; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < p.ktiles;
-    if (more && !(p.ablate & 1)) {
-      advance();
-      load_slice(kt + 1, kh_i, kw_i, c0);
-    }
+  auto compute = [&](int buf) {
     const float* Ab = As + buf * BM * LDK + aoff;
     const float* Bb = Bs + buf * BN * LDK + boff;
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
       f32x4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + ((p.ablate & 4) ? 0 : i * 32 * LDK + pp * 8));
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + ((p.ablate & 4) ? 0 : i * 32 * LDK + koff[pp]));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + ((p.ablate & 4) ? 0 : j * 32 * LDK + pp * 8));
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + ((p.ablate & 4) ? 0 : j * 32 * LDK + koff[pp]));
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -226,120 +209,34 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvK p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     }
-    if (more && !(p.ablate & 2)) store_slice(buf ^ 1);
+  };
+  // one pipeline step: fetch slice kt+2 into the set that held slice kt, multiply slice kt,
+  // park slice kt+1 (other set) in the LDS buffer slice kt-1 just vacated
+  auto step = [&](int kt, f32x4 (&ra_ld)[A_LD], f32x4 (&rb_ld)[B_LD], const f32x4 (&ra_st)[A_LD],
+                  const f32x4 (&rb_st)[B_LD]) {
+    if (kt + 2 < p.ktiles && !(p.ablate & 1)) {
+      advance();
+      load_slice(ra_ld, rb_ld, kt + 2, kh_i, kw_i, c0);
+    }
+    compute(kt & 1);
+    if (kt + 1 < p.ktiles && !(p.ablate & 2)) store_slice(ra_st, rb_st, (kt + 1) & 1);
     if (!(p.ablate & 8)) __syncthreads();
-  }
+  };
 
-  // ---- epilogue.  The accumulators leave the MFMA layout (col = lane & 31,
-  // row = (r&3) + 8*(r>>2) + 4*(lane>>5)) through LDS, so that every lane owns
-  // 16-byte row-major chunks: residual loads and output stores are then
-  // float4-wide and a wave covers whole 512-byte..1-KiB runs of the NHWC row.
-  // (The last main-loop iteration ended with a barrier: the A/B slices are dead.)
-  constexpr int CPR = BN / 4;             // float4 chunks per tile row
-  constexpr int RPP = 256 / CPR;          // rows per pass
-  constexpr int PASSES = BM / RPP;
-  float* Cs = smem;                       // [BM][BN]
-  const int ccol = (tid % CPR) * 4;
-  const int crow = tid / CPR;
-  const int co = tile_n * BN + ccol;
-  const bool vec = p.vec_ok && (co + 3 < p.cout);
-  const long m0 = (long)tile_m * BM + crow;
-
-  f32x4 r1v[PASSES], r2v[PASSES];
-  const bool pre1 = p.res1 != nullptr && !p.res1_resize && vec;
-  const bool pre2 = p.res2 != nullptr && vec;
-  if (pre1) {
-#pragma unroll
-    for (int i = 0; i < PASSES; ++i) {
-      const long m = m0 + (long)i * RPP;
-      r1v[i] = m < p.M ? *reinterpret_cast<const f32x4*>(p.res1 + m * p.res1_ld + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  if (pre2) {
-#pragma unroll
-    for (int i = 0; i < PASSES; ++i) {
-      const long m = m0 + (long)i * RPP;
-      r2v[i] = m < p.M ? *reinterpret_cast<const f32x4*>(p.res2 + m * p.res2_ld + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  {
-    const int half = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const int row = wm * WTM + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-          Cs[row * BN + wn * WTN + j * 32 + (lane & 31)] = acc[i][j][rr];
-        }
+  if (BUF) set_tap(0, 0);
+  load_slice(ra0, rb0, 0, kh_i, kw_i, c0);
+  store_slice(ra0, rb0, 0);
+  if (p.ktiles > 1) {
+    advance();
+    load_slice(ra1, rb1, 1, kh_i, kw_i, c0);
   }
   __syncthreads();
+  for (int kt = 0; kt < p.ktiles; kt += 2) {
+    step(kt, ra0, rb0, ra1, rb1);
+    if (kt + 1 < p.ktiles) step(kt + 1, ra1, rb1, ra0, rb0);
+  }
 
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias != nullptr) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (co + e < p.cout) bias4[e] = p.bias[co + e];
-  }
-#pragma unroll
-  for (int i = 0; i < PASSES; ++i) {
-    const int row = crow + i * RPP;
-    const long m = m0 + (long)i * RPP;
-    if (m >= p.M || co >= p.cout) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * BN + ccol);
-    f32x4 r1 = {0.f, 0.f, 0.f, 0.f}, r2 = {0.f, 0.f, 0.f, 0.f};
-    if (pre1) {
-      r1 = r1v[i];
-    } else if (p.res1 != nullptr) {
-      long roff;
-      if (p.res1_resize) {
-        const int ni = (int)(m / hw);
-        const int rem = (int)(m - (long)ni * hw);
-        const int ho = rem / p.out_w;
-        const int wo = rem - ho * p.out_w;
-        int sh = (int)floorf(ho * p.res1_sh);
-        int sw = (int)floorf(wo * p.res1_sw);
-        sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
-        sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
-        roff = (((long)ni * p.res1_h + sh) * p.res1_w + sw) * p.res1_ld + co;
-      } else {
-        roff = m * p.res1_ld + co;
-      }
-      if (vec) {
-        r1 = *reinterpret_cast<const f32x4*>(p.res1 + roff);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (co + e < p.cout) r1[e] = p.res1[roff + e];
-      }
-    }
-    if (pre2) {
-      r2 = r2v[i];
-    } else if (p.res2 != nullptr) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (co + e < p.cout) r2[e] = p.res2[m * p.res2_ld + co + e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float x = v[e] + bias4[e];
-      if (p.res1 != nullptr && p.res1_pre) x += r1[e];
-      x = x >= 0.f ? x : x * p.act_slope;
-      x = x * p.alpha;
-      if (p.res1 != nullptr && !p.res1_pre) x += r1[e];
-      if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
-      v[e] = x;
-    }
-    float* dst = p.out + m * p.out_ld + co;
-    if (vec) {
-      *reinterpret_cast<f32x4*>(dst) = v;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (co + e < p.cout) dst[e] = v[e];
-    }
-  }
+  conv_epilogue<BN, TM, TN, WTM, WTN>(p, acc, smem, tile_m, tile_n, tid, lane, wm, wn, hw);
 }
 
 template <int BN, bool CIN4, bool BUF>
@@ -381,7 +278,7 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   FCP_REQUIRE(M < (1L << 31), "conv: too many output pixels");
 
   ConvK k;
-  k.in = d->in; k.w = d->w; k.bias = d->bias; k.out = d->out; k.res1 = d->res1; k.res2 = d->res2;
+  k.in = d->in; k.w = reinterpret_cast<const float*>(d->w); k.bias = d->bias; k.wscale = d->wscale; k.out = d->out; k.res1 = d->res1; k.res2 = d->res2;
   k.n = d->n; k.in_h = d->in_h; k.in_w = d->in_w;
   k.ph = d->in_up2 ? d->in_h / 2 : d->in_h;
   k.pw = d->in_up2 ? d->in_w / 2 : d->in_w;
@@ -420,6 +317,14 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   const unsigned long in_bytes = (unsigned long)d->n * k.ph * k.pw * d->in_ld * 4ul;
   const unsigned long w_bytes = (unsigned long)(k.grid_n * d->tile_n) * k.wrow * 4ul;
   const bool buf = in_bytes < 0xFFFFFFF0ul && w_bytes < 0xFFFFFFF0ul;
+  FCP_REQUIRE(d->precision == 0 || d->precision == 1, "conv: precision must be 0 (fp32) or 1 (fp16x3)");
+  if (d->precision == 1) {
+    FCP_REQUIRE(buf, "conv: the fp16x3 path needs tensors below 4 GiB (pack this layer with precision 0)");
+    FCP_REQUIRE(d->wscale != nullptr, "conv: precision 1 needs wscale");
+    k.in_bytes = (unsigned)in_bytes;
+    k.w_bytes = (unsigned)w_bytes;
+    return launch_f16x3(k, d->tile_n, d->cin4 != 0, s);
+  }
   k.in_bytes = buf ? (unsigned)in_bytes : 0u;
   k.w_bytes = buf ? (unsigned)w_bytes : 0u;
 #define FCP_DISPATCH(BN_)                                                             \

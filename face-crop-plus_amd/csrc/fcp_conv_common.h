@@ -1,0 +1,162 @@
+// Shared pieces of the convolution kernels (fp32-exact and fp16x3-split variants):
+// kernel parameter block and the fused epilogue.
+#pragma once
+#include "fcp_common.h"
+#include "fcp_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace fcp_conv {
+
+constexpr int BM = 128;   // output pixels per workgroup tile
+constexpr int BK = 32;    // K slice: one filter tap x 32 input channels
+
+struct ConvK {
+  const float* in;
+  const float* w;
+  const float* bias;
+  float* out;
+  const float* res1;
+  const float* res2;
+  int n, in_h, in_w, ph, pw, cin, in_ld, in_up2;
+  int cout, kh, kw, stride, pad, out_h, out_w, out_ld;
+  int M, ktiles, ctiles, wrow;
+  float act_slope, alpha, alpha2;
+  int res1_pre, res1_ld, res1_h, res1_w, res1_resize, res2_ld;
+  float res1_sh, res1_sw;
+  int grid_m, grid_n, vec_ok;
+  unsigned in_bytes, w_bytes;
+  const float* wscale;  // per-cout power-of-two filter scale (fp16x3 path) or nullptr
+  int ablate;  // profiling-only knob (env FCP_CONV_ABLATE), 0 in production
+};
+
+
+// Fused epilogue, shared by both MFMA variants.  `acc` is in the 32x32 MFMA C/D layout.
+template <int BN, int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], float* smem, int tile_m,
+                                              int tile_n, int tid, int lane, int wm, int wn, int hw) {
+  // ---- epilogue.  The accumulators leave the MFMA layout (col = lane & 31,
+  // row = (r&3) + 8*(r>>2) + 4*(lane>>5)) through LDS, so that every lane owns
+  // 16-byte row-major chunks: residual loads and output stores are then
+  // float4-wide and a wave covers whole 512-byte..1-KiB runs of the NHWC row.
+  // (The last main-loop iteration ended with a barrier: the A/B slices are dead.)
+  constexpr int CPR = BN / 4;             // float4 chunks per tile row
+  constexpr int RPP = 256 / CPR;          // rows per pass
+  constexpr int PASSES = BM / RPP;
+  float* Cs = smem;                       // [BM][BN]
+  const int ccol = (tid % CPR) * 4;
+  const int crow = tid / CPR;
+  const int co = tile_n * BN + ccol;
+  const bool vec = p.vec_ok && (co + 3 < p.cout);
+  const long m0 = (long)tile_m * BM + crow;
+
+  const bool pre1 = p.res1 != nullptr && !p.res1_resize && vec;
+  const bool pre2 = p.res2 != nullptr && vec;
+  {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int row = wm * WTM + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+          Cs[row * BN + wn * WTN + j * 32 + (lane & 31)] = acc[i][j][rr];
+        }
+  }
+  __syncthreads();
+
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, ws4 = {1.f, 1.f, 1.f, 1.f};
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (co + e < p.cout) bias4[e] = p.bias[co + e];
+  }
+  if (p.wscale != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (co + e < p.cout) ws4[e] = p.wscale[co + e];
+  }
+  constexpr int EPC = PASSES < 4 ? PASSES : 4;     // passes per group: bounds the residual registers
+#pragma unroll 1
+  for (int g = 0; g < PASSES; g += EPC) {
+    f32x4 r1v[EPC], r2v[EPC];
+    if (pre1) {
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) {
+        const long m = m0 + (long)(g + i) * RPP;
+        r1v[i] = m < p.M ? *reinterpret_cast<const f32x4*>(p.res1 + m * p.res1_ld + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (pre2) {
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) {
+        const long m = m0 + (long)(g + i) * RPP;
+        r2v[i] = m < p.M ? *reinterpret_cast<const f32x4*>(p.res2 + m * p.res2_ld + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) {
+      const int row = crow + (g + i) * RPP;
+      const long m = m0 + (long)(g + i) * RPP;
+      if (m >= p.M || co >= p.cout) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * BN + ccol);
+      f32x4 r1 = {0.f, 0.f, 0.f, 0.f}, r2 = {0.f, 0.f, 0.f, 0.f};
+      if (pre1) {
+        r1 = r1v[i];
+      } else if (p.res1 != nullptr) {
+        long roff;
+        if (p.res1_resize) {
+          const int ni = (int)(m / hw);
+          const int rem = (int)(m - (long)ni * hw);
+          const int ho = rem / p.out_w;
+          const int wo = rem - ho * p.out_w;
+          int sh = (int)floorf(ho * p.res1_sh);
+          int sw = (int)floorf(wo * p.res1_sw);
+          sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
+          sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
+          roff = (((long)ni * p.res1_h + sh) * p.res1_w + sw) * p.res1_ld + co;
+        } else {
+          roff = m * p.res1_ld + co;
+        }
+        if (vec) {
+          r1 = *reinterpret_cast<const f32x4*>(p.res1 + roff);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.cout) r1[e] = p.res1[roff + e];
+        }
+      }
+      if (pre2) {
+        r2 = r2v[i];
+      } else if (p.res2 != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co + e < p.cout) r2[e] = p.res2[m * p.res2_ld + co + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = v[e] * ws4[e] + bias4[e];
+        if (p.res1 != nullptr && p.res1_pre) x += r1[e];
+        x = x >= 0.f ? x : x * p.act_slope;
+        x = x * p.alpha;
+        if (p.res1 != nullptr && !p.res1_pre) x += r1[e];
+        if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
+        v[e] = x;
+      }
+      float* dst = p.out + m * p.out_ld + co;
+      if (vec) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co + e < p.cout) dst[e] = v[e];
+      }
+    }
+  }
+}
+
+int launch_f16x3(const ConvK& k, int tile_n, bool cin4, hipStream_t s);
+
+}  // namespace fcp_conv

@@ -1,0 +1,276 @@
+// NHWC implicit-GEMM convolution with fp32-equivalent accuracy at the fp16 matrix rate.
+//
+// Every fp32 operand x is split into two binary16 numbers, x = hi + lo (hi = x truncated
+// to 11 significant bits, lo = x - hi, exact, truncated again), and each product is
+// expanded as  a*b ~= ah*bh + ah*bl + al*bh  (the dropped al*bl term is 2^-20 relative),
+// accumulated in fp32 by v_mfma_f32_32x32x16_f16.  Three fp16 MFMAs (16 k-values each)
+// replace eight fp32 MFMAs (2 k-values each): 5.3x the matrix throughput of
+// v_mfma_f32_32x32x2_f32 at ~2^-20 per-product error, i.e. fp32-roundoff class.  Filters
+// are split offline (per-output-channel power-of-two pre-scaling keeps their lo parts out
+// of the fp16 subnormal range; the scale is undone exactly in the epilogue); activations
+// stay fp32 in HBM and are split on the fly while being staged into LDS.
+//
+// Geometry is the fp32 kernel's: 128 x BN tile per 256-thread workgroup, K walked in
+// slices of 32 (one filter tap x 32 channels), raw buffer loads (out-of-range offset ==
+// zero padding), two register sets (prefetch distance of two MFMA phases), two LDS
+// buffers, one barrier per slice, the shared fused epilogue.
+//
+// LDS row image (128 B per pixel / per filter row and slice):
+//   [ hi k0..7 | hi k8..15 | hi k16..23 | hi k24..31 | lo k0..7 | ... | lo k24..31 ]
+// eight 16-byte chunks, XOR-swizzled by (row >> 1) & 7 like the fp32 kernel.  The MFMA
+// operand of lane l for k-step s is chunk 2s + (l >> 5) (hi) / 4 + 2s + (l >> 5) (lo) of
+// row l & 31: one ds_read_b128 each.
+#include "fcp_conv_common.h"
+
+using namespace fcp_conv;
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
+}
+__device__ __forceinline__ u32x4 buf_load16u(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
+}
+
+// 8 fp32 -> 8 hi + 8 lo binary16 (round-toward-zero packs; lo = x - hi is exact in fp32)
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4& hi, u32x4& lo) {
+  const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const auto h2 = __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]);
+    const float r0 = x[2 * q] - (float)h2[0];
+    const float r1 = x[2 * q + 1] - (float)h2[1];
+    const auto l2 = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    hi[q] = __builtin_bit_cast(unsigned, h2);
+    lo[q] = __builtin_bit_cast(unsigned, l2);
+  }
+}
+
+template <int BN, bool CIN4>
+__global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) conv_igemm_f16x3(const ConvK p) {
+  constexpr int WAVES_N = (BN == 32) ? 1 : 2;
+  constexpr int WAVES_M = 4 / WAVES_N;
+  constexpr int WTM = BM / WAVES_M;
+  constexpr int WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int B_LD = BN / 32;       // 16-byte filter chunks per thread per slice
+  constexpr int ROWB = 128;           // LDS bytes per row
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* As = reinterpret_cast<char*>(smem);
+  char* Bs = As + 2 * BM * ROWB;
+
+  const int nb = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_n = logical % p.grid_n;
+  const int tile_m = logical / p.grid_n;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // activation staging: thread -> (row arow + 64*i, 8-channel group ag): two 16-byte loads each
+  const int arow = tid >> 2, ag = tid & 3;
+  // filter staging: bytes are already in LDS image order: thread -> (row brow + 32*i, chunk bc)
+  const int brow = tid >> 3, bc = tid & 7;
+
+  unsigned pbase[2];
+  int hi0[2], wi0[2];
+  const int hw = p.out_h * p.out_w;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = tile_m * BM + arow + 64 * i;
+    if (m < p.M) {
+      const int ni = m / hw;
+      const int rem = m - ni * hw;
+      const int ho = rem / p.out_w;
+      const int wo = rem - ho * p.out_w;
+      pbase[i] = (unsigned)(ni * p.ph * p.pw);
+      hi0[i] = ho * p.stride - p.pad;
+      wi0[i] = wo * p.stride - p.pad;
+    } else {
+      pbase[i] = 0;
+      hi0[i] = -(1 << 28);
+      wi0[i] = 0;
+    }
+  }
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+  unsigned woff[B_LD];
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((tile_n * BN + brow + 32 * i) * p.wrow + bc * 4) * 4);
+
+  // byte offsets of this thread's two 16-byte pieces at channel 0 of the current tap
+  unsigned rowoff[2][2];
+  auto set_tap = [&](int kh_i, int kw_i) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int hi = hi0[i] + kh_i;
+        int wi = wi0[i] + (CIN4 ? 2 * ag + h : kw_i);
+        const bool ok = (unsigned)hi < (unsigned)p.in_h && (unsigned)wi < (unsigned)p.in_w;
+        if (p.in_up2) { hi >>= 1; wi >>= 1; }
+        const unsigned pix = pbase[i] + (unsigned)(hi * p.pw + wi);
+        rowoff[i][h] = ok ? (pix * (unsigned)p.in_ld + (CIN4 ? 0u : (unsigned)(ag * 8 + h * 4))) * 4u : 0xFFFFFFFFu;
+      }
+    }
+  };
+
+  f32x4 ra0[4], ra1[4];
+  u32x4 rb0[B_LD], rb1[B_LD];
+  auto load_slice = [&](f32x4 (&ra)[4], u32x4 (&rb)[B_LD], int kt, int c0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned ro = rowoff[i][h];
+        ra[2 * i + h] = buf_load16(rs_in, ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4));
+      }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) rb[i] = buf_load16u(rs_w, woff[i] + (unsigned)(kt * BK * 4));
+  };
+  const int asw = (arow >> 1) & 7;   // (row + 64 i) >> 1 & 7 is the same for both rows
+  const int bsw = (brow >> 1) & 7;
+  auto store_slice = [&](const f32x4 (&ra)[4], const u32x4 (&rb)[B_LD], int buf) {
+    char* a = As + buf * BM * ROWB + arow * ROWB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u32x4 hi, lo;
+      split8(ra[2 * i], ra[2 * i + 1], hi, lo);
+      *reinterpret_cast<u32x4*>(a + 64 * i * ROWB + ((ag ^ asw) << 4)) = hi;
+      *reinterpret_cast<u32x4*>(a + 64 * i * ROWB + (((4 + ag) ^ asw) << 4)) = lo;
+    }
+    char* b = Bs + buf * BN * ROWB + brow * ROWB + ((bc ^ bsw) << 4);
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) *reinterpret_cast<u32x4*>(b + 32 * i * ROWB) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int kh_i = 0, kw_i = 0, c0 = 0;
+  auto advance = [&]() {
+    if (CIN4) {
+      ++kh_i;
+      set_tap(kh_i, 0);
+    } else {
+      c0 += BK;
+      if (c0 >= p.cin) {
+        c0 = 0;
+        if (++kw_i >= p.kw) { kw_i = 0; ++kh_i; }
+        set_tap(kh_i, kw_i);
+      }
+    }
+  };
+
+  const int aoff = (wm * WTM + (lane & 31)) * ROWB;
+  const int boff = (wn * WTN + (lane & 31)) * ROWB;
+  const int rsw = ((lane & 31) >> 1) & 7;
+  const int half = lane >> 5;
+  int offH[2], offL[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    offH[s] = ((2 * s + half) ^ rsw) << 4;
+    offL[s] = ((4 + 2 * s + half) ^ rsw) << 4;
+  }
+
+  auto compute = [&](int buf) {
+    const char* Ab = As + buf * BM * ROWB + aoff;
+    const char* Bb = Bs + buf * BN * ROWB + boff;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * ROWB + offH[s]);
+        al[i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * ROWB + offL[s]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(Bb + j * 32 * ROWB + offH[s]);
+        bl[j] = *reinterpret_cast<const f16x8*>(Bb + j * 32 * ROWB + offL[s]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  auto step = [&](int kt, f32x4 (&ra_ld)[4], u32x4 (&rb_ld)[B_LD], const f32x4 (&ra_st)[4],
+                  const u32x4 (&rb_st)[B_LD]) {
+    if (kt + 2 < p.ktiles) {
+      advance();
+      load_slice(ra_ld, rb_ld, kt + 2, c0);
+    }
+    compute(kt & 1);
+    if (kt + 1 < p.ktiles) store_slice(ra_st, rb_st, (kt + 1) & 1);
+    __syncthreads();
+  };
+
+  set_tap(0, 0);
+  load_slice(ra0, rb0, 0, c0);
+  store_slice(ra0, rb0, 0);
+  if (p.ktiles > 1) {
+    advance();
+    load_slice(ra1, rb1, 1, c0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < p.ktiles; kt += 2) {
+    step(kt, ra0, rb0, ra1, rb1);
+    if (kt + 1 < p.ktiles) step(kt + 1, ra1, rb1, ra0, rb0);
+  }
+
+  conv_epilogue<BN, TM, TN, WTM, WTN>(p, acc, smem, tile_m, tile_n, tid, lane, wm, wn, hw);
+}
+
+template <int BN, bool CIN4>
+int launch(const ConvK& k, hipStream_t s) {
+  static bool attr_set = false;
+  const size_t lds = (size_t)2 * (BM + BN) * 128;
+  if (!attr_set) {
+    FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16x3<BN, CIN4>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_f16x3<BN, CIN4>), dim3(k.grid_m * k.grid_n), dim3(256), lds, s, k);
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace
+
+namespace fcp_conv {
+
+int launch_f16x3(const ConvK& k, int tile_n, bool cin4, hipStream_t s) {
+  if (cin4) {
+    switch (tile_n) {
+      case 32: return launch<32, true>(k, s);
+      case 64: return launch<64, true>(k, s);
+      default: return launch<128, true>(k, s);
+    }
+  }
+  switch (tile_n) {
+    case 32: return launch<32, false>(k, s);
+    case 64: return launch<64, false>(k, s);
+    default: return launch<128, false>(k, s);
+  }
+}
+
+}  // namespace fcp_conv

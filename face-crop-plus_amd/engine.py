@@ -69,6 +69,8 @@ class PackedConv:
     pad: int
     cin4: bool
     flops_per_pixel: int     # 2*cout*cin*kh*kw (algorithmic, unpadded)
+    precision: int = 0       # 0 fp32 exact, 1 fp16x3 split
+    wscale: torch.Tensor | None = None
 
 
 def fold_bn(weight: np.ndarray, bn: dict | None, bias: np.ndarray | None):
@@ -85,8 +87,58 @@ def fold_bn(weight: np.ndarray, bn: dict | None, bias: np.ndarray | None):
     return (w * alpha[:, None, None, None]).astype(f), beta
 
 
-def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, device="cuda", cin_perm=None) -> PackedConv:
-    """weight: (cout,cin,kh,kw) numpy/torch; bn: dict with weight/bias/running_mean/running_var."""
+import contextlib
+import os
+
+PRECISIONS = {"f32": 0, "fp32": 0, "exact": 0, 0: 0, "f16x3": 1, "fp16x3": 1, 1: 1}
+# module-wide default for pack_conv(precision=None): env FCP_PRECISION = f32 | f16x3
+DEFAULT_PRECISION = PRECISIONS[os.environ.get("FCP_PRECISION", "f16x3")]
+
+
+def resolve_precision(p):
+    if p is None:
+        return DEFAULT_PRECISION
+    if p not in PRECISIONS:
+        raise ValueError(f"unknown precision {p!r}: use 'f32' (exact fp32 MFMA) or 'f16x3' (split fp16 MFMA)")
+    return PRECISIONS[p]
+
+
+@contextlib.contextmanager
+def default_precision(p):
+    """Temporarily set the precision ``pack_conv`` uses when none is given."""
+    global DEFAULT_PRECISION
+    prev, DEFAULT_PRECISION = DEFAULT_PRECISION, resolve_precision(p)
+    try:
+        yield
+    finally:
+        DEFAULT_PRECISION = prev
+
+
+
+def split_f16x3(packed: np.ndarray):
+    """fp32 packed filter [cout_pad][K] -> (uint16 image with, per 32 K values, 32 hi + 32 lo
+    binary16 numbers, wscale).  Rows are pre-scaled by 2^-floor(log2(max|w|)) so the lo parts stay
+    normal in binary16; ``wscale`` (= 2^e per row) undoes the scaling exactly in the epilogue."""
+    rows = packed.reshape(packed.shape[0], -1).astype(np.float32)
+    amax = np.abs(rows).max(1)
+    e = np.where(amax > 0, np.floor(np.log2(np.maximum(amax, 1e-38))), 0.0)
+    scale = np.exp2(e).astype(np.float32)
+    ws = rows / scale[:, None]
+    hi = ws.astype(np.float16)
+    lo = (ws - hi.astype(np.float32)).astype(np.float16)
+    k = rows.shape[1]
+    assert k % 32 == 0
+    img = np.empty((rows.shape[0], k // 32, 2, 32), np.float16)
+    img[:, :, 0] = hi.reshape(rows.shape[0], k // 32, 32)
+    img[:, :, 1] = lo.reshape(rows.shape[0], k // 32, 32)
+    return img.reshape(rows.shape[0], k * 2).view(np.uint16), scale
+
+
+def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, device="cuda", cin_perm=None,
+              precision: int | None = None) -> PackedConv:
+    """weight: (cout,cin,kh,kw) numpy/torch; bn: dict with weight/bias/running_mean/running_var.
+    ``precision``: 0 = exact fp32 MFMA, 1 = fp16x3 split MFMA (None: ``DEFAULT_PRECISION``)."""
+    precision = resolve_precision(precision)
     if isinstance(weight, torch.Tensor):
         weight = weight.detach().cpu().numpy()
     if isinstance(bias, torch.Tensor):
@@ -107,10 +159,16 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, device="cuda", cin_pe
         assert cin % 32 == 0, f"cin={cin} must be a multiple of 32"
         packed = np.zeros((cout_pad, kh, kw, cin), np.float32)
         packed[:cout] = w.transpose(0, 2, 3, 1)
-    wd = torch.from_numpy(np.ascontiguousarray(packed)).to(device)
+    wsc = None
+    if precision == 1:
+        img, scale = split_f16x3(packed)
+        wd = torch.from_numpy(np.ascontiguousarray(img.view(np.int16))).to(device)
+        wsc = torch.from_numpy(scale).to(device)
+    else:
+        wd = torch.from_numpy(np.ascontiguousarray(packed)).to(device)
     bd = None if b is None else torch.from_numpy(np.ascontiguousarray(b)).to(device)
     return PackedConv(wd, bd, 4 if cin4 else cin, cout, kh, kw, stride, pad, cin4,
-                      2 * cout * cin * kh * kw)
+                      2 * cout * cin * kh * kw, precision, wsc)
 
 
 def bn_of(sd, prefix):
@@ -125,6 +183,32 @@ def _pick_tile_n(cout: int, m: int) -> int:
     if cout % 128 == 0 and gm * (cout // 128) >= 512:
         return 128
     return 64
+
+
+class Autotune:
+    """Optional per-shape choice of the N tile: the first launch of an unseen conv shape times the
+    candidate tiles with HIP events (costs a sync, so only during warm-up) and caches the winner."""
+    enabled = False
+    cache: dict = {}
+
+    @classmethod
+    def pick(cls, key, candidates, launch):
+        best = cls.cache.get(key)
+        if best is not None:
+            return best
+        times = []
+        for t in candidates:
+            launch(t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                launch(t)
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+        best = candidates[int(np.argmin(times))]
+        cls.cache[key] = best
+        return best
 
 
 class ConvStats:
@@ -157,6 +241,8 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     d = N.ConvDesc()
     d.in_, d.w, d.out = x.ptr(), N.ptr(pc.w), out.ptr()
     d.bias = N.ptr(pc.bias)
+    d.wscale = N.ptr(pc.wscale)
+    d.precision = pc.precision
     d.res1 = res1.ptr() if res1 is not None else None
     d.res2 = res2.ptr() if res2 is not None else None
     d.n, d.in_h, d.in_w = x.n, in_h, in_w
@@ -173,6 +259,13 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     if res2 is not None:
         assert (res2.n, res2.h, res2.w, res2.c) == (x.n, oh, ow, pc.cout)
         d.res2_ld = res2.ld
+    if tile_n is None and Autotune.enabled and pc.cout > 64:
+        def _launch(t):
+            d.tile_n = t
+            N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
+        key = (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, m, int(in_up2), res1 is not None, res2 is not None,
+               pc.precision)
+        d.tile_n = Autotune.pick(key, [64, 128], _launch)
     timing = ConvStats.timing
     if timing is not None:
         e0 = torch.cuda.Event(enable_timing=True)

@@ -36,10 +36,11 @@ class RetinaFace:
         self._p = None
 
     # ------------------------------------------------------------------ load
-    def load(self, device: str | torch.device = "cuda:0", weights=None):
+    def load(self, device: str | torch.device = "cuda:0", weights=None, precision=None):
         """Pack the state dict for the HIP engine (reference ``LoadMixin.load``,
         _layers.py:16-25).  ``weights``: None (real checkpoint if present, else the
-        deterministic generator), a path, a state dict, or "generated"."""
+        deterministic generator), a path, a state dict, or "generated".  ``precision``:
+        "f16x3" (split-fp16 MFMA, fp32-equivalent accuracy, default) or "f32" (exact fp32 MFMA)."""
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("face_crop_plus_amd runs on an AMD GPU only (device must be cuda:N / hip); "
@@ -47,8 +48,9 @@ class RetinaFace:
         N.lib()  # fail loudly now if the extension is missing
         self.device = device
         sd = load_state_dict("retinaface", weights)
-        with torch.cuda.device(device):
+        with torch.cuda.device(device), E.default_precision(precision):
             self._p = self._pack(sd, device)
+        self.precision = E.resolve_precision(precision)
         return self
 
     @staticmethod

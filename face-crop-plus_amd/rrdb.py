@@ -28,16 +28,20 @@ class RRDBNet:
         self.device = None
         self._p = None
 
-    def load(self, device="cuda:0", weights=None):
+    def load(self, device="cuda:0", weights=None, precision=None):
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("face_crop_plus_amd runs on an AMD GPU only; there is no CPU fallback")
         N.lib()
         self.device = device
         sd = load_state_dict("rrdb", weights)
-        with torch.cuda.device(device):
-            pc = lambda k: E.pack_conv(sd[k + ".weight"], sd[k + ".bias"], None, 1, 1, device)
-            p = {k: pc(k) for k in ("conv_first", "trunk_conv", "upconv1", "upconv2", "HRconv", "conv_last")}
+        with torch.cuda.device(device), E.default_precision(precision):
+            pc = lambda k, prec=None: E.pack_conv(sd[k + ".weight"], sd[k + ".bias"], None, 1, 1, device,
+                                                  precision=prec)
+            p = {k: pc(k) for k in ("conv_first", "trunk_conv", "upconv1", "upconv2")}
+            # the x4-resolution tail reads a 64-channel tensor of 4 GiB at 1024^2 inputs: beyond the
+            # 32-bit buffer addressing of the f16x3 kernel, so these two always use the fp32 kernel
+            p["HRconv"], p["conv_last"] = pc("HRconv", "f32"), pc("conv_last", "f32")
             p["trunk"] = [[[pc(f"RRDB_trunk.{t}.RDB{r}.conv{c}") for c in range(1, 6)] for r in (1, 2, 3)]
                           for t in range(self.NUM_BLOCKS)]
             self._p = p

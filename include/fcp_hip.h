@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 1
+#define FCP_ABI_VERSION 2
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -31,7 +31,13 @@ int fcp_abi_version(void);
 const char* fcp_last_error(void);
 
 /* ------------------------------------------------------------------------
- * Convolution engine (NHWC fp32 implicit GEMM on v_mfma_f32_32x32x2_f32).
+ * Convolution engine (NHWC fp32 tensors, implicit GEMM on the matrix cores).
+ * Two arithmetic modes, chosen per filter at pack time (`precision`):
+ *   0  exact fp32:  v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain;
+ *   1  fp16x3 split: every operand x = hi + lo (two binary16), product expanded as
+ *      ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_f16 with fp32 accumulation:
+ *      ~2^-20 relative error per product (fp32-roundoff class) at 5.3x the matrix rate.
+ *      Filter rows are pre-scaled by a power of two (`wscale` undoes it exactly).
  * Replaces every nn.Conv2d(+BatchNorm eval)(+ReLU/LeakyReLU)(+residual) the
  * three networks dispatch to ATen: models/_layers.py:64-162 (SSH/FPN/Head),
  * :168-200 (RRDB blocks), :206-368 (BiSeNet blocks), torchvision ResNet-50
@@ -45,6 +51,8 @@ const char* fcp_last_error(void);
  * Filter layout (produced by the host packer, see engine.py pack_conv):
  *   normal mode : [cout_pad][kh][kw][cin]            cin % 32 == 0
  *   cin4 mode   : [cout_pad][kh][8][4]               cin <= 4, kw <= 8
+ * precision 0 stores fp32; precision 1 stores, for every 32 consecutive K values of a
+ * row, 32 binary16 hi parts followed by 32 binary16 lo parts (same 128 bytes).
  * cout_pad = cout rounded up to the N tile (32/64/128) chosen by `tile_n`;
  * the padding rows are zero.  BatchNorm (eval) is folded into w and bias.
  *
@@ -61,11 +69,12 @@ const char* fcp_last_error(void);
  * ------------------------------------------------------------------------ */
 typedef struct fcp_conv_desc {
   const float* in;    /* (n, in_h_phys, in_w_phys, in_ld) */
-  const float* w;     /* packed filter */
+  const void* w;      /* packed filter */
   const float* bias;  /* [cout] or NULL */
   float* out;         /* (n, out_h, out_w, out_ld) */
   const float* res1;  /* or NULL */
   const float* res2;  /* or NULL */
+  const float* wscale; /* [cout] power-of-two filter scales (precision 1) or NULL */
   int32_t n, in_h, in_w; /* logical input size (after the optional x2 upsample) */
   int32_t cin, in_ld;
   int32_t in_up2;     /* 1: physical input is (in_h/2, in_w/2), read at (h>>1, w>>1)
@@ -77,6 +86,7 @@ typedef struct fcp_conv_desc {
   int32_t cin4;       /* 1: cin4 mode */
   float act_slope, alpha, alpha2;
   int32_t res1_pre, res1_ld, res1_h, res1_w, res2_ld;
+  int32_t precision;  /* 0 = fp32 exact, 1 = fp16x3 split (filter packed accordingly) */
 } fcp_conv_desc;
 
 int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);

@@ -7,6 +7,14 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["f32", "f16x3"], autouse=True)
+def precision(request):
+    """Every conv test runs on both arithmetic paths (exact fp32 MFMA / split-fp16 MFMA)."""
+    from face_crop_plus_amd import engine as E
+    with E.default_precision(request.param):
+        yield request.param
+
+
 def _nhwc(x, device):  # NCHW cpu -> NHWC device
     return x.permute(0, 2, 3, 1).contiguous().to(device)
 

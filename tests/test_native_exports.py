@@ -34,11 +34,11 @@ def test_conv_desc_layout_matches_header():
         decl = decl.strip()
         if not decl:
             continue
-        names = re.sub(r"^(const\s+)?(float|int32_t)\s*\*?", "", decl)
+        names = re.sub(r"^(const\s+)?(float|int32_t|void)\s*\*?", "", decl)
         fields += [n.strip().lstrip("*") for n in names.split(",")]
     mine = [f[0].rstrip("_") for f in N.ConvDesc._fields_]
     assert fields == mine
-    assert ctypes.sizeof(N.ConvDesc) == 6 * 8 + 24 * 4
+    assert ctypes.sizeof(N.ConvDesc) == 7 * 8 + 26 * 4
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
