@@ -31,6 +31,7 @@ import numpy as np
 import torch
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (not the 2:1-sparse figure)
 RETINA_GFLOP_1024 = 226.64      # algorithmic FLOP / image @1024^2 (scales with H*W)
 
 
@@ -45,6 +46,8 @@ def parse():
     ap.add_argument("--strategy", default="largest")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
+                    help="conv arithmetic: split-fp16 MFMA (fp32-equivalent accuracy) or exact fp32 MFMA")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batch is split over")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
@@ -74,7 +77,7 @@ def main():
     if world > 1:
         from face_crop_plus_amd.dist import broadcast_state_dict
         sd = broadcast_state_dict(sd, dev)
-    det = RetinaFace(args.strategy, 0.6).load(dev, sd)
+    det = RetinaFace(args.strategy, 0.6).load(dev, sd, args.precision)
     from face_crop_plus_amd.cropper import landmarks_target
     tgt = torch.from_numpy(landmarks_target((args.out_size, args.out_size), 0.65)).to(dev)
 
@@ -156,14 +159,21 @@ def main():
         traffic, traffic_src = None, None
         prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_conv.json")) \
             if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        prof = [f for f in prof if ("f16x3" in f) == (args.precision == "f16x3")]
         if prof and args.batch == 64 and args.size == 640:
             # HBM bytes per conv launch from the committed rocprofv3 --pmc passes of this same command
             with open(os.path.join(ROOT, "profiles", prof[-1])) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch"])
             traffic_src = "profiles/" + prof[-1]
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        split = args.precision == "f16x3"
+        peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        roofline = {"bound": "mfma",
+                    "kernel": ("conv_igemm_f16x3 (3x v_mfma_f32_32x32x16_f16 per product: x = hi + lo split)" if split
+                               else "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)"),
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4),
+                    # the split path executes 3 matrix FLOP per algorithmic FLOP: utilisation of the f16 pipe
+                    "executed_frac": round(achieved * (3 if split else 1) / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per conv launch (PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                     "traffic_source": traffic_src,
                     "launches_per_step": launches, "algorithmic_gflop_per_step": round(conv_flops / 1e9, 2),
@@ -179,7 +189,8 @@ def main():
             "metric": "faces/sec end-to-end (detect+align+crop)",
             "value": round(total_faces / elapsed, 2), "unit": "faces/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16x3" if args.precision == "f16x3" else "f32",
             "data": "synthetic (uniform uint8 images resident in HBM; seeded random-init weights; file I/O excluded)",
             "config": {"workload": f"RetinaFace detect + 5-pt align/crop, batch={args.batch}/GPU synthetic "
                                    f"{args.size}x{args.size} RGB, strategy={args.strategy}, det_threshold=0.6, "

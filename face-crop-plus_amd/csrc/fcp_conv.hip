@@ -106,15 +106,27 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
     for (int i = 0; i < B_LD; ++i)
       woff[i] = (unsigned)(((tile_n * BN + lrow + 32 * i) * p.wrow + chunk * 4) * 4);
   }
-  auto set_tap = [&](int kh_i, int kw_i) {
+  TapPiece tp[A_LD];
+  if (BUF) {
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      int hi = hi0[i] + kh_i;
-      int wi = wi0[i] + (CIN4 ? chunk : kw_i);
-      const bool ok = (unsigned)hi < (unsigned)p.in_h && (unsigned)wi < (unsigned)p.in_w;
-      if (p.in_up2) { hi >>= 1; wi >>= 1; }
-      const unsigned pix = pbase[i] + (unsigned)(hi * p.pw + wi);
-      rowoff[i] = ok ? (pix * (unsigned)p.in_ld + (CIN4 ? 0u : (unsigned)(chunk * 4))) * 4u : 0xFFFFFFFFu;
+    for (int i = 0; i < A_LD; ++i)
+      tp[i] = make_tap_piece<CIN4>(p, pbase[i], hi0[i], wi0[i] + (CIN4 ? chunk : 0), CIN4 ? 0u : (unsigned)(chunk * 4));
+  }
+  auto set_tap = [&](int tap, int kh_i, int kw_i) {
+    if (p.in_up2) {   // nearest-x2 operand fetch: physical offset is not linear in the tap
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        int hi = hi0[i] + kh_i;
+        int wi = wi0[i] + (CIN4 ? chunk : kw_i);
+        const bool ok = (unsigned)hi < (unsigned)p.in_h && (unsigned)wi < (unsigned)p.in_w;
+        hi >>= 1; wi >>= 1;
+        const unsigned pix = pbase[i] + (unsigned)(hi * p.pw + wi);
+        rowoff[i] = ok ? (pix * (unsigned)p.in_ld + (CIN4 ? 0u : (unsigned)(chunk * 4))) * 4u : 0xFFFFFFFFu;
+      }
+    } else {
+      const unsigned tapoff = (unsigned)((kh_i * p.pw + kw_i) * p.in_ld) * 4u;   // wave-uniform
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) rowoff[i] = ((tp[i].mask >> tap) & 1u) ? tp[i].base + tapoff : 0xFFFFFFFFu;
     }
   };
 
@@ -169,19 +181,16 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  int kh_i = 0, kw_i = 0, c0 = 0;
-  auto advance = [&]() {
+  int tap = 0, kh_i = 0, kw_i = 0, c0 = 0;
+  auto advance = [&]() {      // next slice: taps fastest, then the 32-channel slice
+    ++tap;
     if (CIN4) {
       ++kh_i;
-      if (BUF) set_tap(kh_i, 0);
-    } else {
-      c0 += BK;
-      if (c0 >= p.cin) {
-        c0 = 0;
-        if (++kw_i >= p.kw) { kw_i = 0; ++kh_i; }
-        if (BUF) set_tap(kh_i, kw_i);
-      }
+    } else if (++kw_i >= p.kw) {
+      kw_i = 0;
+      if (++kh_i >= p.kh) { kh_i = 0; tap = 0; c0 += BK; }
     }
+    if (BUF) set_tap(tap, kh_i, kw_i);
   };
 
   const int aoff = (wm * WTM + (lane & 31)) * LDK;
@@ -223,7 +232,7 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
     if (!(p.ablate & 8)) __syncthreads();
   };
 
-  if (BUF) set_tap(0, 0);
+  if (BUF) set_tap(0, 0, 0);
   load_slice(ra0, rb0, 0, kh_i, kw_i, c0);
   store_slice(ra0, rb0, 0);
   if (p.ktiles > 1) {
@@ -262,6 +271,7 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   FCP_REQUIRE(d->n > 0 && d->in_h > 0 && d->in_w > 0 && d->cout > 0, "conv: bad sizes");
   FCP_REQUIRE(d->tile_n == 32 || d->tile_n == 64 || d->tile_n == 128, "conv: tile_n must be 32/64/128");
   FCP_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->pad >= 0, "conv: bad filter geometry");
+  FCP_REQUIRE(d->kh * d->kw <= 32 || d->cin4, "conv: at most 32 filter taps (kh*kw) outside cin4 mode");
   FCP_REQUIRE(d->in_ld % 4 == 0 && ((uintptr_t)d->in & 15) == 0, "conv: input must be 16-byte aligned, in_ld %% 4 == 0");
   FCP_REQUIRE(((uintptr_t)d->w & 15) == 0, "conv: filter must be 16-byte aligned");
   if (d->cin4) {

@@ -32,6 +32,32 @@ struct ConvK {
 };
 
 
+// K order: slice kt = (channel slice kt / taps, tap kt % taps): the kh*kw taps of one 32-channel
+// slice are consecutive, so a 3x3 conv touches only 32 channels of its pixel neighbourhood for 9
+// slices in a row — the per-XCD working set stays L2 resident instead of being re-fetched per tap.
+//
+// Operand addressing per 16-byte piece: `base` = byte offset of the piece at tap (0,0), channel 0
+// (wrapping unsigned arithmetic; only used when valid) and `mask` bit t = tap t reads a real pixel
+// (not the zero padding).  Per slice the offset is base + tap_off(uniform) + c0*4, or 0xFFFFFFFF.
+struct TapPiece {
+  unsigned base, mask;
+};
+
+template <bool CIN4>
+__device__ __forceinline__ TapPiece make_tap_piece(const ConvK& p, unsigned pbase, int hi0, int wi0, unsigned chan_off) {
+  TapPiece t;
+  t.base = ((pbase + (unsigned)(hi0 * p.pw + wi0)) * (unsigned)p.in_ld + chan_off) * 4u;
+  t.mask = 0u;
+  const int taps = CIN4 ? p.kh : p.kh * p.kw;
+  for (int q = 0; q < taps; ++q) {
+    const int kh_i = CIN4 ? q : q / p.kw;
+    const int kw_i = CIN4 ? 0 : q - kh_i * p.kw;
+    const bool ok = (unsigned)(hi0 + kh_i) < (unsigned)p.in_h && (unsigned)(wi0 + kw_i) < (unsigned)p.in_w;
+    t.mask |= ok ? (1u << q) : 0u;
+  }
+  return t;
+}
+
 // Fused epilogue, shared by both MFMA variants.  `acc` is in the 32x32 MFMA C/D layout.
 template <int BN, int TM, int TN, int WTM, int WTN>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], float* smem, int tile_m,

@@ -107,20 +107,35 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
 #pragma unroll
   for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((tile_n * BN + brow + 32 * i) * p.wrow + bc * 4) * 4);
 
-  // byte offsets of this thread's two 16-byte pieces at channel 0 of the current tap
-  unsigned rowoff[2][2];
-  auto set_tap = [&](int kh_i, int kw_i) {
+  // this thread's four 16-byte activation pieces: (row i, half h)
+  TapPiece tp[2][2];
+  unsigned rowoff[2][2];   // byte offset at channel 0 of the current tap, 0xFFFFFFFF = zero padding
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int hi = hi0[i] + kh_i;
-        int wi = wi0[i] + (CIN4 ? 2 * ag + h : kw_i);
-        const bool ok = (unsigned)hi < (unsigned)p.in_h && (unsigned)wi < (unsigned)p.in_w;
-        if (p.in_up2) { hi >>= 1; wi >>= 1; }
-        const unsigned pix = pbase[i] + (unsigned)(hi * p.pw + wi);
-        rowoff[i][h] = ok ? (pix * (unsigned)p.in_ld + (CIN4 ? 0u : (unsigned)(ag * 8 + h * 4))) * 4u : 0xFFFFFFFFu;
-      }
+    for (int h = 0; h < 2; ++h)
+      tp[i][h] = make_tap_piece<CIN4>(p, pbase[i], hi0[i], wi0[i] + (CIN4 ? 2 * ag + h : 0),
+                                      CIN4 ? 0u : (unsigned)(ag * 8 + h * 4));
+  auto set_tap = [&](int tap, int kh_i, int kw_i) {
+    if (p.in_up2) {   // nearest-x2 operand fetch: physical offset is not linear in the tap
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          int hi = hi0[i] + kh_i;
+          int wi = wi0[i] + (CIN4 ? 2 * ag + h : kw_i);
+          const bool ok = (unsigned)hi < (unsigned)p.in_h && (unsigned)wi < (unsigned)p.in_w;
+          hi >>= 1; wi >>= 1;
+          const unsigned pix = pbase[i] + (unsigned)(hi * p.pw + wi);
+          rowoff[i][h] = ok ? (pix * (unsigned)p.in_ld + (CIN4 ? 0u : (unsigned)(ag * 8 + h * 4))) * 4u : 0xFFFFFFFFu;
+        }
+    } else {
+      const unsigned tapoff = (unsigned)((kh_i * p.pw + kw_i) * p.in_ld) * 4u;   // wave-uniform
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          rowoff[i][h] = ((tp[i][h].mask >> tap) & 1u) ? tp[i][h].base + tapoff : 0xFFFFFFFFu;
     }
   };
 
@@ -144,7 +159,8 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       u32x4 hi, lo;
-      split8(ra[2 * i], ra[2 * i + 1], hi, lo);
+      if (p.ablate & 16) { hi = __builtin_bit_cast(u32x4, ra[2 * i]); lo = __builtin_bit_cast(u32x4, ra[2 * i + 1]); }
+      else split8(ra[2 * i], ra[2 * i + 1], hi, lo);
       *reinterpret_cast<u32x4*>(a + 64 * i * ROWB + ((ag ^ asw) << 4)) = hi;
       *reinterpret_cast<u32x4*>(a + 64 * i * ROWB + (((4 + ag) ^ asw) << 4)) = lo;
     }
@@ -161,19 +177,16 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  int kh_i = 0, kw_i = 0, c0 = 0;
-  auto advance = [&]() {
+  int tap = 0, kh_i = 0, kw_i = 0, c0 = 0;
+  auto advance = [&]() {      // next slice: taps fastest, then the 32-channel slice
+    ++tap;
     if (CIN4) {
       ++kh_i;
-      set_tap(kh_i, 0);
-    } else {
-      c0 += BK;
-      if (c0 >= p.cin) {
-        c0 = 0;
-        if (++kw_i >= p.kw) { kw_i = 0; ++kh_i; }
-        set_tap(kh_i, kw_i);
-      }
+    } else if (++kw_i >= p.kw) {
+      kw_i = 0;
+      if (++kh_i >= p.kh) { kh_i = 0; tap = 0; c0 += BK; }
     }
+    set_tap(tap, kh_i, kw_i);
   };
 
   const int aoff = (wm * WTM + (lane & 31)) * ROWB;
@@ -195,13 +208,13 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
       f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * ROWB + offH[s]);
-        al[i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * ROWB + offL[s]);
+        ah[i] = *reinterpret_cast<const f16x8*>(Ab + ((p.ablate & 4) ? 0 : i * 32 * ROWB + offH[s]));
+        al[i] = *reinterpret_cast<const f16x8*>(Ab + ((p.ablate & 4) ? 16 : i * 32 * ROWB + offL[s]));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8*>(Bb + j * 32 * ROWB + offH[s]);
-        bl[j] = *reinterpret_cast<const f16x8*>(Bb + j * 32 * ROWB + offL[s]);
+        bh[j] = *reinterpret_cast<const f16x8*>(Bb + ((p.ablate & 4) ? 0 : j * 32 * ROWB + offH[s]));
+        bl[j] = *reinterpret_cast<const f16x8*>(Bb + ((p.ablate & 4) ? 16 : j * 32 * ROWB + offL[s]));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -215,16 +228,16 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
   };
   auto step = [&](int kt, f32x4 (&ra_ld)[4], u32x4 (&rb_ld)[B_LD], const f32x4 (&ra_st)[4],
                   const u32x4 (&rb_st)[B_LD]) {
-    if (kt + 2 < p.ktiles) {
+    if (kt + 2 < p.ktiles && !(p.ablate & 1)) {
       advance();
       load_slice(ra_ld, rb_ld, kt + 2, c0);
     }
     compute(kt & 1);
-    if (kt + 1 < p.ktiles) store_slice(ra_st, rb_st, (kt + 1) & 1);
-    __syncthreads();
+    if (kt + 1 < p.ktiles && !(p.ablate & 2)) store_slice(ra_st, rb_st, (kt + 1) & 1);
+    if (!(p.ablate & 8)) __syncthreads();
   };
 
-  set_tap(0, 0);
+  set_tap(0, 0, 0);
   load_slice(ra0, rb0, 0, c0);
   store_slice(ra0, rb0, 0);
   if (p.ktiles > 1) {

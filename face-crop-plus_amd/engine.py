@@ -157,8 +157,9 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, device="cuda", cin_pe
         packed[:cout, :, :kw, :cin] = w.transpose(0, 2, 3, 1)
     else:
         assert cin % 32 == 0, f"cin={cin} must be a multiple of 32"
-        packed = np.zeros((cout_pad, kh, kw, cin), np.float32)
-        packed[:cout] = w.transpose(0, 2, 3, 1)
+        # K order (cin/32, kh, kw, 32): the taps of one 32-channel slice are consecutive
+        packed = np.zeros((cout_pad, cin // 32, kh, kw, 32), np.float32)
+        packed[:cout] = w.transpose(0, 2, 3, 1).reshape(cout, kh, kw, cin // 32, 32).transpose(0, 3, 1, 2, 4)
     wsc = None
     if precision == 1:
         img, scale = split_f16x3(packed)

@@ -49,7 +49,8 @@ const char* fcp_last_error(void);
  * is how torch.cat (SSH, dense blocks, FFM) is realised with no copy.
  *
  * Filter layout (produced by the host packer, see engine.py pack_conv):
- *   normal mode : [cout_pad][kh][kw][cin]            cin % 32 == 0
+ *   normal mode : [cout_pad][cin/32][kh][kw][32]     cin % 32 == 0 (taps of one 32-channel
+ *                                                    slice are consecutive in K: L2 locality)
  *   cin4 mode   : [cout_pad][kh][8][4]               cin <= 4, kw <= 8
  * precision 0 stores fp32; precision 1 stores, for every 32 consecutive K values of a
  * row, 32 binary16 hi parts followed by 32 binary16 lo parts (same 128 bytes).

@@ -35,8 +35,9 @@ out = {
     "hbm_bytes_per_launch": (fetch_kib * read_corr + write_kib) * 1024 / LAUNCHES,
     "mfma_busy_cycles": mfma_busy, "grbm_gui_active_sum_8xcd": gui,
     "mfma_util": mfma_busy / (gui / 8 * 1024),
-    "note": "SQ_VALU_MFMA_BUSY_CYCLES = 64 cycles per v_mfma_f32_32x32x2_f32 summed over 1024 SIMDs (includes "
-            "zero-padded cout / stem-K work); GRBM_GUI_ACTIVE is summed over the 8 XCDs",
+    "note": "SQ_VALU_MFMA_BUSY_CYCLES = matrix-pipe busy cycles summed over the 1024 SIMDs (64 per "
+            "v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_32x32x16_f16; includes zero-padded cout / stem-K work); "
+            "GRBM_GUI_ACTIVE is summed over the 8 XCDs, so mfma_util = busy / (gui/8 * 1024)",
 }
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
