@@ -40,8 +40,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
-    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--workload", default="detect", choices=["detect", "full"],
+                    help="detect = BASELINE configs[1] (detect+align+crop, the headline metric); "
+                         "full = configs[2] (detect + RRDB enhance + align + BiSeNet parse, batch 32 @1024)")
+    ap.add_argument("--enhance", default="all", choices=["all", "none", "rule"],
+                    help="workload=full: which images go through RRDB (all / none / the reference's face-area rule)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (64 detect / 32 full)")
+    ap.add_argument("--size", type=int, default=None, help="image side (640 detect / 1024 full)")
     ap.add_argument("--out-size", type=int, default=256)
     ap.add_argument("--strategy", default="largest")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -55,6 +60,11 @@ def parse():
 
 def main():
     args = parse()
+    full = args.workload == "full"
+    if args.batch is None:
+        args.batch = 32 if full else 64
+    if args.size is None:
+        args.size = 1024 if full else 640
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,10 +98,29 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [None]
     chunks = list(torch.chunk(images, len(streams)))
 
+    enh = par = None
+    if full:
+        from face_crop_plus_amd.rrdb import RRDBNet
+        from face_crop_plus_amd.bise import BiSeNet
+        if args.enhance != "none":
+            enh = RRDBNet(0.001).load(dev, weights.generate_state_dict("rrdb"), args.precision)
+        par = BiSeNet({"glasses": [6]}, {"eyes": [4, 5]}, 32).load(dev, weights.generate_state_dict("bisenet"),
+                                                                   args.precision)
+
     def step_chunk(imgs, count):
         res = det.detect(imgs, max_faces=imgs.shape[0] if args.strategy != "all" else None)
+        if enh is not None:
+            imgs = imgs.clone()                      # enhancement rewrites the batch in place
+            which = list(range(imgs.shape[0]))
+            if args.enhance == "rule":               # rrdb.py:124-140 needs the landmarks on the host
+                nf_h = int(res["face_offset"][-1].item())
+                which = enh.gate(imgs.shape[0], imgs.shape[1], imgs.shape[2], res["landmarks"][:nf_h].cpu().numpy(),
+                                 res["img_idx"][:nf_h].cpu().tolist())
+            enh.enhance_u8(imgs, which)
         crops, ok, _ = align.crop_align(imgs, res["img_idx"], res["landmarks"], tgt,
                                         (args.out_size, args.out_size), 0)
+        if par is not None:
+            par.parse(crops)                         # label maps + class histograms stay on the device
         if count:
             nf = torch.clamp(res["face_offset"][-1].to(torch.int64), max=res["max_faces"])
             valid = (torch.arange(res["max_faces"], device=dev) < nf) & (ok != 0)
@@ -192,7 +221,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3" if args.precision == "f16x3" else "f32",
             "data": "synthetic (uniform uint8 images resident in HBM; seeded random-init weights; file I/O excluded)",
-            "config": {"workload": f"RetinaFace detect + 5-pt align/crop, batch={args.batch}/GPU synthetic "
+            "config": {"workload": (f"full pipeline (detect + RRDB enhance[{args.enhance}] + align + BiSeNet parse)" if full
+                                    else "RetinaFace detect + 5-pt align/crop") +
+                                   f", batch={args.batch}/GPU synthetic "
                                    f"{args.size}x{args.size} RGB, strategy={args.strategy}, det_threshold=0.6, "
                                    f"output {args.out_size}x{args.out_size}",
                        "global_batch": args.batch * world, "image_size": args.size, "parallelism": f"dp{world}",

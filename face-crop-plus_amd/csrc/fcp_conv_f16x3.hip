@@ -152,15 +152,17 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) rb[i] = buf_load16u(rs_w, woff[i] + (unsigned)(kt * BK * 4));
   };
-  const int asw = (arow >> 1) & 7;   // (row + 64 i) >> 1 & 7 is the same for both rows
-  const int bsw = (brow >> 1) & 7;
+  // chunk swizzle sw(row) = ((row >> 1) & 7) ^ ((row & 1) << 2): ds_read_b128 (64 banks) sees 16 distinct
+  // slots per 16-lane group, and the activation stores below — an 8-lane ds_write_b128 group is rows r, r+1
+  // x 4 chunks, banks (addr/4) % 32 so rows 128 B apart alias — land in opposite halves of the row.
+  const int asw = ((arow >> 1) & 7) ^ ((arow & 1) << 2);   // identical for rows arow and arow + 64
+  const int bsw = ((brow >> 1) & 7) ^ ((brow & 1) << 2);
   auto store_slice = [&](const f32x4 (&ra)[4], const u32x4 (&rb)[B_LD], int buf) {
     char* a = As + buf * BM * ROWB + arow * ROWB;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       u32x4 hi, lo;
-      if (p.ablate & 16) { hi = __builtin_bit_cast(u32x4, ra[2 * i]); lo = __builtin_bit_cast(u32x4, ra[2 * i + 1]); }
-      else split8(ra[2 * i], ra[2 * i + 1], hi, lo);
+      split8(ra[2 * i], ra[2 * i + 1], hi, lo);
       *reinterpret_cast<u32x4*>(a + 64 * i * ROWB + ((ag ^ asw) << 4)) = hi;
       *reinterpret_cast<u32x4*>(a + 64 * i * ROWB + (((4 + ag) ^ asw) << 4)) = lo;
     }
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
 
   const int aoff = (wm * WTM + (lane & 31)) * ROWB;
   const int boff = (wn * WTN + (lane & 31)) * ROWB;
-  const int rsw = ((lane & 31) >> 1) & 7;
+  const int rsw = (((lane & 31) >> 1) & 7) ^ ((lane & 1) << 2);
   const int half = lane >> 5;
   int offH[2], offL[2];
 #pragma unroll
@@ -200,41 +202,91 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
     offL[s] = ((4 + 2 * s + half) ^ rsw) << 4;
   }
 
-  auto compute = [&](int buf) {
-    const char* Ab = As + buf * BM * ROWB + aoff;
-    const char* Bb = Bs + buf * BN * ROWB + boff;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8*>(Ab + ((p.ablate & 4) ? 0 : i * 32 * ROWB + offH[s]));
-        al[i] = *reinterpret_cast<const f16x8*>(Ab + ((p.ablate & 4) ? 16 : i * 32 * ROWB + offL[s]));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8*>(Bb + ((p.ablate & 4) ? 0 : j * 32 * ROWB + offH[s]));
-        bl[j] = *reinterpret_cast<const f16x8*>(Bb + ((p.ablate & 4) ? 16 : j * 32 * ROWB + offL[s]));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
-  };
+  // ---- one pipeline step, hand-interleaved -------------------------------------------------
+  // The wave's instruction stream is in order, so matrix work and the split (VALU) + LDS store of
+  // the next slice only overlap if they alternate in program order.  A step is therefore emitted
+  // as NM = 2*TM*TN*3 MFMAs with, behind every MFMA, a few "pieces" of the conversion pipeline of
+  // slice kt+1 (registers that landed an iteration ago): per float pair A: pack hi, B: unpack hi,
+  // C: residual, D: pack lo — two pairs in flight so dependent pieces are an MFMA apart.
+  // sched_barrier(0) pins the order (the scheduler otherwise clusters all MFMAs first).
+  constexpr int MF = TM * TN * 3;   // MFMAs per k-step
+  constexpr int NM = 2 * MF;        // MFMAs per slice
+  constexpr int NP = 35;            // conversion pieces: 8 pairs x 4 stages + 2 activation stores + filter store
   auto step = [&](int kt, f32x4 (&ra_ld)[4], u32x4 (&rb_ld)[B_LD], const f32x4 (&ra_st)[4],
                   const u32x4 (&rb_st)[B_LD]) {
-    if (kt + 2 < p.ktiles && !(p.ablate & 1)) {
+    if (kt + 2 < p.ktiles) {
       advance();
       load_slice(ra_ld, rb_ld, kt + 2, c0);
     }
-    compute(kt & 1);
-    if (kt + 1 < p.ktiles && !(p.ablate & 2)) store_slice(ra_st, rb_st, (kt + 1) & 1);
-    if (!(p.ablate & 8)) __syncthreads();
+    const int buf = kt & 1, nbuf = buf ^ 1;
+    const char* Ab = As + buf * BM * ROWB + aoff;
+    const char* Bb = Bs + buf * BN * ROWB + boff;
+    char* a_st = As + nbuf * BM * ROWB + arow * ROWB;
+    char* b_st = Bs + nbuf * BN * ROWB + brow * ROWB + ((bc ^ bsw) << 4);
+
+    f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    auto read_frags = [&](int st) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[st][i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * ROWB + offH[st]);
+        al[st][i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * ROWB + offL[st]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[st][j] = *reinterpret_cast<const f16x8*>(Bb + j * 32 * ROWB + offH[st]);
+        bl[st][j] = *reinterpret_cast<const f16x8*>(Bb + j * 32 * ROWB + offL[st]);
+      }
+    };
+    // conversion state of the 8 float pairs of this thread (pairs 0-3: row arow, 4-7: row arow+64)
+    decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h2[8], l2[8];
+    float r0[8], r1[8];
+    auto xval = [&](int pr, int e) -> float { return ra_st[pr >> 1][(pr & 1) * 2 + e]; };
+    // (runs unconditionally: on the last slice it converts stale registers into the idle LDS stage,
+    //  which nobody reads — a branch here would split the block and undo the interleave)
+    auto piece = [&](int pc) {
+      if (pc == 16 || pc == 33) {          // activation rows: hi and lo chunks
+        const int row = pc == 16 ? 0 : 1;
+        u32x4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          hi[q] = __builtin_bit_cast(unsigned, h2[row * 4 + q]);
+          lo[q] = __builtin_bit_cast(unsigned, l2[row * 4 + q]);
+        }
+        *reinterpret_cast<u32x4*>(a_st + 64 * row * ROWB + ((ag ^ asw) << 4)) = hi;
+        *reinterpret_cast<u32x4*>(a_st + 64 * row * ROWB + (((4 + ag) ^ asw) << 4)) = lo;
+        return;
+      }
+      if (pc == 34) {                      // filter rows (already split offline): plain copy
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) *reinterpret_cast<u32x4*>(b_st + 32 * i * ROWB) = rb_st[i];
+        return;
+      }
+      const int g = pc < 16 ? pc : pc - 1;             // 0..31 over the four 8-piece groups
+      const int pr = (g >> 3) * 2 + (g & 1);           // pair index 0..7
+      const int stage = (g & 7) >> 1;
+      if (stage == 0) h2[pr] = __builtin_amdgcn_cvt_pkrtz(xval(pr, 0), xval(pr, 1));
+      else if (stage == 1) { r0[pr] = (float)h2[pr][0]; r1[pr] = (float)h2[pr][1]; }
+      else if (stage == 2) { r0[pr] = xval(pr, 0) - r0[pr]; r1[pr] = xval(pr, 1) - r1[pr]; }
+      else l2[pr] = __builtin_amdgcn_cvt_pkrtz(r0[pr], r1[pr]);
+    };
+
+    read_frags(0);
+    read_frags(1);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const int st = m / MF, idx = m % MF;
+      const int ij = idx / 3, term = idx % 3;
+      const int i = ij / TN, j = ij % TN;
+      // smallest contributions first: al*bh, ah*bl, ah*bh
+      const f16x8 fa = term == 0 ? al[st][i] : ah[st][i];
+      const f16x8 fb = term == 1 ? bl[st][j] : bh[st][j];
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pc = m * NP / NM; pc < (m + 1) * NP / NM; ++pc) piece(pc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
   };
 
   set_tap(0, 0, 0);
