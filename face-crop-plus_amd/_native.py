@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_f32p = C.c_void_p
 _lib = None
@@ -31,6 +31,7 @@ class ConvDesc(C.Structure):
         ("act_slope", C.c_float), ("alpha", C.c_float), ("alpha2", C.c_float),
         ("res1_pre", C.c_int32), ("res1_ld", C.c_int32), ("res1_h", C.c_int32),
         ("res1_w", C.c_int32), ("res2_ld", C.c_int32), ("precision", C.c_int32),
+        ("in_fmt", C.c_int32), ("out_fmt", C.c_int32), ("res1_fmt", C.c_int32), ("res2_fmt", C.c_int32),
     ]
 
 
@@ -41,6 +42,9 @@ SIGNATURES = {
     "fcp_u8_to_nhwc4_f32": [_P, _P, _L, C.POINTER(C.c_float), _F, _P],
     "fcp_f32nchw_to_nhwc4_f32": [_P, _P, _I, _I, _I, C.POINTER(C.c_float), _F, _P],
     "fcp_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "fcp_maxpool3x3s2_split32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "fcp_f32_to_split32": [_P, _P, _L, _I, _P],
+    "fcp_split32_to_f32": [_P, _P, _L, _I, _P],
     "fcp_retina_decode": [_P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "fcp_retina_nms_select": [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
     "fcp_retina_gather_faces": [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P],

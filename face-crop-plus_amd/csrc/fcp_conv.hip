@@ -305,6 +305,21 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   k.res1_pre = d->res1_pre; k.res1_ld = d->res1_ld; k.res2_ld = d->res2_ld;
   k.res1_h = d->res1_h; k.res1_w = d->res1_w;
   k.res1_resize = 0; k.res1_sh = 1.f; k.res1_sw = 1.f;
+  k.in_fmt = d->in_fmt; k.out_fmt = d->out_fmt; k.res1_fmt = d->res1 ? d->res1_fmt : 0; k.res2_fmt = d->res2 ? d->res2_fmt : 0;
+  const int any_split = k.in_fmt | k.out_fmt | k.res1_fmt | k.res2_fmt;
+  FCP_REQUIRE((unsigned)any_split <= 1u, "conv: tensor formats must be 0 (fp32) or 1 (split32)");
+  if (any_split) {
+    FCP_REQUIRE(d->precision == 1, "conv: split32 tensors need precision 1 (fp16x3 kernel)");
+    FCP_REQUIRE(d->cout % 8 == 0, "conv: split32 epilogue needs cout %% 8 == 0");
+    FCP_REQUIRE(!k.in_fmt || (!d->cin4 && d->in_ld % 32 == 0 && ((uintptr_t)d->in & 127) == 0),
+                "conv: split32 input must be a 32-channel-group aligned view (in_ld %% 32 == 0), not cin4");
+    FCP_REQUIRE(!k.out_fmt || (d->out_ld % 32 == 0 && ((uintptr_t)d->out & 127) == 0 && d->cout % 32 == 0),
+                "conv: split32 output must be a 32-channel-group aligned view with cout %% 32 == 0");
+    FCP_REQUIRE(!k.res1_fmt || (d->res1_ld % 32 == 0 && ((uintptr_t)d->res1 & 127) == 0), "conv: misaligned split32 res1");
+    FCP_REQUIRE(!k.res2_fmt || (d->res2_ld % 32 == 0 && ((uintptr_t)d->res2 & 127) == 0), "conv: misaligned split32 res2");
+    FCP_REQUIRE(((uintptr_t)d->out & 15) == 0 && d->out_ld % 4 == 0 && (!d->res1 || (((uintptr_t)d->res1 & 15) == 0 && d->res1_ld % 4 == 0)) &&
+                (!d->res2 || (((uintptr_t)d->res2 & 15) == 0 && d->res2_ld % 4 == 0)), "conv: 8-channel epilogue needs 16-byte aligned tensors");
+  }
   if (d->res1) {
     FCP_REQUIRE(d->res1_h > 0 && d->res1_w > 0 && d->res1_ld > 0, "conv: res1 geometry missing");
     if (d->res1_h != d->out_h || d->res1_w != d->out_w) {

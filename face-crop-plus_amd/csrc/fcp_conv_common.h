@@ -28,6 +28,7 @@ struct ConvK {
   int grid_m, grid_n, vec_ok;
   unsigned in_bytes, w_bytes;
   const float* wscale;  // per-cout power-of-two filter scale (fp16x3 path) or nullptr
+  int in_fmt, out_fmt, res1_fmt, res2_fmt;   // 0 = fp32 NHWC, 1 = split32 (see fcp_hip.h)
   int ablate;  // profiling-only knob (env FCP_CONV_ABLATE), 0 in production
 };
 
@@ -179,6 +180,134 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
         for (int e = 0; e < 4; ++e)
           if (co + e < p.cout) dst[e] = v[e];
       }
+    }
+  }
+}
+
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+// 8 fp32 -> 8 hi + 8 lo binary16 (round-toward-zero packs; lo = x - hi is exact in fp32).  Idempotent on
+// values that already are a hi + lo sum, so elementwise kernels may decode / re-encode freely.
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4_t& hi, u32x4_t& lo) {
+  const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const auto h2 = __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]);
+    const float r0 = x[2 * q] - (float)h2[0];
+    const float r1 = x[2 * q + 1] - (float)h2[1];
+    const auto l2 = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    hi[q] = __builtin_bit_cast(unsigned, h2);
+    lo[q] = __builtin_bit_cast(unsigned, l2);
+  }
+}
+// inverse: value = float(hi) + float(lo) (exact)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void join8(const u32x4_t& hi, const u32x4_t& lo, float (&x)[8]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned hu = hi[q], lu = lo[q];
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, hu);
+    const f16x2_t l = __builtin_bit_cast(f16x2_t, lu);
+    x[2 * q] = (float)h[0] + (float)l[0];
+    x[2 * q + 1] = (float)h[1] + (float)l[1];
+  }
+}
+// byte offset of channel c (multiple of 8) inside a split32 pixel: group (c/32)*128 B, hi at (c%32)*2, lo +64
+__device__ __forceinline__ long split_chan_off(int c) { return (long)(c >> 5) * 128 + (c & 31) * 2; }
+
+// 8 consecutive channels of one pixel from an activation tensor of either format
+__device__ __forceinline__ void load8(const float* base, long pix, int ld, int c, int fmt, float (&x)[8]) {
+  if (fmt == 1) {
+    const char* pb = reinterpret_cast<const char*>(base) + pix * ld * 4 + split_chan_off(c);
+    join8(*reinterpret_cast<const u32x4_t*>(pb), *reinterpret_cast<const u32x4_t*>(pb + 64), x);
+  } else {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(base + pix * ld + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(base + pix * ld + c + 4);
+    x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+  }
+}
+
+// Epilogue for 8-channel granularity: used whenever the output or a residual is in split32 format
+// (cout % 8 == 0, all tensors 16-byte aligned).  Same arithmetic as conv_epilogue.
+template <int BN, int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void conv_epilogue8(const ConvK& p, f32x16 (&acc)[TM][TN], float* smem, int tile_m,
+                                               int tile_n, int tid, int lane, int wm, int wn, int hw) {
+  constexpr int CPR = BN / 8;
+  constexpr int RPP = 256 / CPR;
+  constexpr int PASSES = BM / RPP;
+  float* Cs = smem;
+  const int ccol = (tid % CPR) * 8;
+  const int crow = tid / CPR;
+  const int co = tile_n * BN + ccol;
+  const long m0 = (long)tile_m * BM + crow;
+  {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int row = wm * WTM + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+          Cs[row * BN + wn * WTN + j * 32 + (lane & 31)] = acc[i][j][rr];
+        }
+  }
+  __syncthreads();
+  if (co >= p.cout) return;
+  float bias8[8], ws8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bias8[e] = p.bias != nullptr ? p.bias[co + e] : 0.f;
+    ws8[e] = p.wscale != nullptr ? p.wscale[co + e] : 1.f;
+  }
+#pragma unroll 2
+  for (int g = 0; g < PASSES; ++g) {
+    const int row = crow + g * RPP;
+    const long m = m0 + (long)g * RPP;
+    if (m >= p.M) continue;
+    float v[8], r1[8], r2[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * BN + ccol);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * BN + ccol + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+    if (p.res1 != nullptr) {
+      long rpix = m;
+      if (p.res1_resize) {
+        const int ni = (int)(m / hw);
+        const int rem = (int)(m - (long)ni * hw);
+        const int ho = rem / p.out_w;
+        const int wo = rem - ho * p.out_w;
+        int sh = (int)floorf(ho * p.res1_sh);
+        int sw = (int)floorf(wo * p.res1_sw);
+        sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
+        sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
+        rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
+      }
+      load8(p.res1, rpix, p.res1_ld, co, p.res1_fmt, r1);
+    }
+    if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, co, p.res2_fmt, r2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = v[e] * ws8[e] + bias8[e];
+      if (p.res1 != nullptr && p.res1_pre) x += r1[e];
+      x = x >= 0.f ? x : x * p.act_slope;
+      x = x * p.alpha;
+      if (p.res1 != nullptr && !p.res1_pre) x += r1[e];
+      if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
+      v[e] = x;
+    }
+    if (p.out_fmt == 1) {
+      u32x4_t hi, lo;
+      split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+      char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + split_chan_off(co);
+      *reinterpret_cast<u32x4_t*>(ob) = hi;
+      *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
+    } else {
+      float* dst = p.out + m * p.out_ld + co;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
     }
   }
 }

@@ -27,7 +27,7 @@ using namespace fcp_conv;
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4_t u32x4;
 
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
@@ -36,22 +36,12 @@ __device__ __forceinline__ u32x4 buf_load16u(__amdgpu_buffer_rsrc_t rsrc, unsign
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
 }
 
-// 8 fp32 -> 8 hi + 8 lo binary16 (round-toward-zero packs; lo = x - hi is exact in fp32)
-__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4& hi, u32x4& lo) {
-  const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const auto h2 = __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]);
-    const float r0 = x[2 * q] - (float)h2[0];
-    const float r1 = x[2 * q + 1] - (float)h2[1];
-    const auto l2 = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-    hi[q] = __builtin_bit_cast(unsigned, h2);
-    lo[q] = __builtin_bit_cast(unsigned, l2);
-  }
-}
-
-template <int BN, bool CIN4>
+// ASPLIT: the activation tensor is already in split32 format (hi/lo binary16 planes per 32 channels):
+// a K slice of a pixel is then byte-for-byte the LDS row image and is staged as a plain copy, exactly
+// like the filter; otherwise (fp32 input) it is split on the fly.
+template <int BN, bool CIN4, bool ASPLIT>
 __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) conv_igemm_f16x3(const ConvK p) {
+  static_assert(!(CIN4 && ASPLIT), "the 3-channel stems always read fp32");
   constexpr int WAVES_N = (BN == 32) ? 1 : 2;
   constexpr int WAVES_M = 4 / WAVES_N;
   constexpr int WTM = BM / WAVES_M;
@@ -107,15 +97,16 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
 #pragma unroll
   for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((tile_n * BN + brow + 32 * i) * p.wrow + bc * 4) * 4);
 
-  // this thread's four 16-byte activation pieces: (row i, half h)
+  // this thread's four 16-byte activation pieces: (row i, half h).  fp32 input: channels 8ag+4h..+3 of the
+  // slice; split32 input: chunk ag of the hi plane (h = 0) / of the lo plane (h = 1), in 4-byte units
+  auto achan = [&](int h) -> unsigned { return ASPLIT ? (unsigned)(h * 16 + ag * 4) : (unsigned)(ag * 8 + h * 4); };
   TapPiece tp[2][2];
   unsigned rowoff[2][2];   // byte offset at channel 0 of the current tap, 0xFFFFFFFF = zero padding
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-      tp[i][h] = make_tap_piece<CIN4>(p, pbase[i], hi0[i], wi0[i] + (CIN4 ? 2 * ag + h : 0),
-                                      CIN4 ? 0u : (unsigned)(ag * 8 + h * 4));
+      tp[i][h] = make_tap_piece<CIN4>(p, pbase[i], hi0[i], wi0[i] + (CIN4 ? 2 * ag + h : 0), CIN4 ? 0u : achan(h));
   auto set_tap = [&](int tap, int kh_i, int kw_i) {
     if (p.in_up2) {   // nearest-x2 operand fetch: physical offset is not linear in the tap
 #pragma unroll
@@ -127,7 +118,7 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
           const bool ok = (unsigned)hi < (unsigned)p.in_h && (unsigned)wi < (unsigned)p.in_w;
           hi >>= 1; wi >>= 1;
           const unsigned pix = pbase[i] + (unsigned)(hi * p.pw + wi);
-          rowoff[i][h] = ok ? (pix * (unsigned)p.in_ld + (CIN4 ? 0u : (unsigned)(ag * 8 + h * 4))) * 4u : 0xFFFFFFFFu;
+          rowoff[i][h] = ok ? (pix * (unsigned)p.in_ld + (CIN4 ? 0u : achan(h))) * 4u : 0xFFFFFFFFu;
         }
     } else {
       const unsigned tapoff = (unsigned)((kh_i * p.pw + kw_i) * p.in_ld) * 4u;   // wave-uniform
@@ -162,7 +153,8 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       u32x4 hi, lo;
-      split8(ra[2 * i], ra[2 * i + 1], hi, lo);
+      if (ASPLIT) { hi = __builtin_bit_cast(u32x4, ra[2 * i]); lo = __builtin_bit_cast(u32x4, ra[2 * i + 1]); }
+      else split8(ra[2 * i], ra[2 * i + 1], hi, lo);
       *reinterpret_cast<u32x4*>(a + 64 * i * ROWB + ((ag ^ asw) << 4)) = hi;
       *reinterpret_cast<u32x4*>(a + 64 * i * ROWB + (((4 + ag) ^ asw) << 4)) = lo;
     }
@@ -247,10 +239,15 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
       if (pc == 16 || pc == 33) {          // activation rows: hi and lo chunks
         const int row = pc == 16 ? 0 : 1;
         u32x4 hi, lo;
+        if (ASPLIT) {
+          hi = __builtin_bit_cast(u32x4, ra_st[2 * row]);
+          lo = __builtin_bit_cast(u32x4, ra_st[2 * row + 1]);
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          hi[q] = __builtin_bit_cast(unsigned, h2[row * 4 + q]);
-          lo[q] = __builtin_bit_cast(unsigned, l2[row * 4 + q]);
+          for (int q = 0; q < 4; ++q) {
+            hi[q] = __builtin_bit_cast(unsigned, h2[row * 4 + q]);
+            lo[q] = __builtin_bit_cast(unsigned, l2[row * 4 + q]);
+          }
         }
         *reinterpret_cast<u32x4*>(a_st + 64 * row * ROWB + ((ag ^ asw) << 4)) = hi;
         *reinterpret_cast<u32x4*>(a_st + 64 * row * ROWB + (((4 + ag) ^ asw) << 4)) = lo;
@@ -261,6 +258,7 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
         for (int i = 0; i < B_LD; ++i) *reinterpret_cast<u32x4*>(b_st + 32 * i * ROWB) = rb_st[i];
         return;
       }
+      if (ASPLIT) return;                              // nothing to convert: the copy is the store above
       const int g = pc < 16 ? pc : pc - 1;             // 0..31 over the four 8-piece groups
       const int pr = (g >> 3) * 2 + (g & 1);           // pair index 0..7
       const int stage = (g & 7) >> 1;
@@ -302,19 +300,22 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
     if (kt + 1 < p.ktiles) step(kt + 1, ra1, rb1, ra0, rb0);
   }
 
-  conv_epilogue<BN, TM, TN, WTM, WTN>(p, acc, smem, tile_m, tile_n, tid, lane, wm, wn, hw);
+  if (p.out_fmt | p.res1_fmt | p.res2_fmt)
+    conv_epilogue8<BN, TM, TN, WTM, WTN>(p, acc, smem, tile_m, tile_n, tid, lane, wm, wn, hw);
+  else
+    conv_epilogue<BN, TM, TN, WTM, WTN>(p, acc, smem, tile_m, tile_n, tid, lane, wm, wn, hw);
 }
 
-template <int BN, bool CIN4>
+template <int BN, bool CIN4, bool ASPLIT>
 int launch(const ConvK& k, hipStream_t s) {
   static bool attr_set = false;
   const size_t lds = (size_t)2 * (BM + BN) * 128;
   if (!attr_set) {
-    FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16x3<BN, CIN4>),
+    FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16x3<BN, CIN4, ASPLIT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_f16x3<BN, CIN4>), dim3(k.grid_m * k.grid_n), dim3(256), lds, s, k);
+  hipLaunchKernelGGL((conv_igemm_f16x3<BN, CIN4, ASPLIT>), dim3(k.grid_m * k.grid_n), dim3(256), lds, s, k);
   FCP_LAUNCH_OK();
   return 0;
 }
@@ -326,15 +327,22 @@ namespace fcp_conv {
 int launch_f16x3(const ConvK& k, int tile_n, bool cin4, hipStream_t s) {
   if (cin4) {
     switch (tile_n) {
-      case 32: return launch<32, true>(k, s);
-      case 64: return launch<64, true>(k, s);
-      default: return launch<128, true>(k, s);
+      case 32: return launch<32, true, false>(k, s);
+      case 64: return launch<64, true, false>(k, s);
+      default: return launch<128, true, false>(k, s);
+    }
+  }
+  if (k.in_fmt == 1) {
+    switch (tile_n) {
+      case 32: return launch<32, false, true>(k, s);
+      case 64: return launch<64, false, true>(k, s);
+      default: return launch<128, false, true>(k, s);
     }
   }
   switch (tile_n) {
-    case 32: return launch<32, false>(k, s);
-    case 64: return launch<64, false>(k, s);
-    default: return launch<128, false>(k, s);
+    case 32: return launch<32, false, false>(k, s);
+    case 64: return launch<64, false, false>(k, s);
+    default: return launch<128, false, false>(k, s);
   }
 }
 

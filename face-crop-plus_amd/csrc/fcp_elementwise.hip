@@ -1,8 +1,7 @@
 // HBM-bound glue kernels of the detector body: uint8 -> fp32 NHWC4 conversion
 // (mean subtraction / scaling fused) and the stem max-pool.  One 16-byte store
 // per lane, grid-stride, >= 2048 workgroups when the tensor is large enough.
-#include "fcp_common.h"
-#include "fcp_hip.h"
+#include "fcp_conv_common.h"
 
 #include <cstdarg>
 #include <cstring>
@@ -21,7 +20,10 @@ extern "C" int fcp_abi_version(void) { return FCP_ABI_VERSION; }
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using fcp_conv::join8;
+using fcp_conv::split8;
+using fcp_conv::split_chan_off;
+using fcp_conv::u32x4_t;
 
 // 4 pixels (12 bytes in, 64 bytes out) per thread iteration.
 __global__ void __launch_bounds__(256) u8_to_nhwc4_kernel(const uint8_t* __restrict__ in,
@@ -102,6 +104,74 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float* __restri
   }
 }
 
+// split32 tensors: one thread per (pixel, 8-channel chunk)
+__global__ void __launch_bounds__(256) maxpool3x3s2_split_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                 int n, int h, int w, int c, int oh, int ow) {
+  const int c8 = c >> 3;
+  const long total = (long)n * oh * ow * c8;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const char* ib = reinterpret_cast<const char*>(in);
+  char* ob = reinterpret_cast<char*>(out);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int ch = (int)(i % c8) * 8;
+    long t = i / c8;
+    const int x = (int)(t % ow);
+    t /= ow;
+    const int y = (int)(t % oh);
+    const int ni = (int)(t / oh);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = 2 * y - 1 + dy;
+      if ((unsigned)yy >= (unsigned)h) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = 2 * x - 1 + dx;
+        if ((unsigned)xx >= (unsigned)w) continue;
+        const char* pb = ib + (((long)ni * h + yy) * w + xx) * c * 4 + split_chan_off(ch);
+        float v[8];
+        join8(*reinterpret_cast<const u32x4_t*>(pb), *reinterpret_cast<const u32x4_t*>(pb + 64), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+    u32x4_t hi, lo;
+    split8(f32x4{m[0], m[1], m[2], m[3]}, f32x4{m[4], m[5], m[6], m[7]}, hi, lo);
+    char* qb = ob + (((long)ni * oh + y) * ow + x) * c * 4 + split_chan_off(ch);
+    *reinterpret_cast<u32x4_t*>(qb) = hi;
+    *reinterpret_cast<u32x4_t*>(qb + 64) = lo;
+  }
+}
+
+template <bool TO_SPLIT>
+__global__ void __launch_bounds__(256) split_convert_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            long npix, int c) {
+  const int c8 = c >> 3;
+  const long total = npix * c8;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int ch = (int)(i % c8) * 8;
+    const long pix = i / c8;
+    if (TO_SPLIT) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(in + pix * c + ch);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(in + pix * c + ch + 4);
+      u32x4_t hi, lo;
+      split8(a, b, hi, lo);
+      char* qb = reinterpret_cast<char*>(out) + pix * c * 4 + split_chan_off(ch);
+      *reinterpret_cast<u32x4_t*>(qb) = hi;
+      *reinterpret_cast<u32x4_t*>(qb + 64) = lo;
+    } else {
+      const char* pb = reinterpret_cast<const char*>(in) + pix * c * 4 + split_chan_off(ch);
+      float v[8];
+      join8(*reinterpret_cast<const u32x4_t*>(pb), *reinterpret_cast<const u32x4_t*>(pb + 64), v);
+      *reinterpret_cast<f32x4*>(out + pix * c + ch) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(out + pix * c + ch + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+}
+
 inline int grid_for(long work_items, int block) {
   long g = (work_items + block - 1) / block;
   if (g > 8192) g = 8192;
@@ -144,6 +214,35 @@ extern "C" int fcp_maxpool3x3s2_nhwc_f32(const float* in, float* out, int n, int
   const long total = (long)n * out_h * out_w * (c / 4);
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
                      out, n, h, w, c / 4, out_h, out_w);
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int fcp_maxpool3x3s2_split32(const float* in, float* out, int n, int h, int w, int c, int out_h,
+                                        int out_w, fcp_stream_t stream) {
+  FCP_REQUIRE(in && out, "maxpool: null pointer");
+  FCP_REQUIRE(c % 32 == 0 && ((uintptr_t)in & 127) == 0 && ((uintptr_t)out & 127) == 0,
+              "maxpool(split32): c must be a multiple of 32 and buffers 128-byte aligned");
+  FCP_REQUIRE(out_h == (h + 2 - 3) / 2 + 1 && out_w == (w + 2 - 3) / 2 + 1, "maxpool: bad output size");
+  const long total = (long)n * out_h * out_w * (c / 8);
+  hipLaunchKernelGGL(maxpool3x3s2_split_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     out, n, h, w, c, out_h, out_w);
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int fcp_f32_to_split32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream) {
+  FCP_REQUIRE(in && out && npix > 0 && c > 0 && c % 32 == 0, "f32_to_split32: bad arguments (c %% 32 == 0)");
+  hipLaunchKernelGGL(split_convert_kernel<true>, dim3(grid_for(npix * (c / 8), 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, (long)npix, c);
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int fcp_split32_to_f32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream) {
+  FCP_REQUIRE(in && out && npix > 0 && c > 0 && c % 32 == 0, "split32_to_f32: bad arguments (c %% 32 == 0)");
+  hipLaunchKernelGGL(split_convert_kernel<false>, dim3(grid_for(npix * (c / 8), 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, (long)npix, c);
   FCP_LAUNCH_OK();
   return 0;
 }

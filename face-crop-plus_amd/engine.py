@@ -25,17 +25,21 @@ class Act:
     is how ``torch.cat`` along channels is realised without a copy: producers
     write their slice, consumers read a wider slice.
     """
-    __slots__ = ("buf", "c0", "c")
+    __slots__ = ("buf", "c0", "c", "fmt")
 
-    def __init__(self, buf: torch.Tensor, c0: int = 0, c: int | None = None):
+    def __init__(self, buf: torch.Tensor, c0: int = 0, c: int | None = None, fmt: int = 0):
+        """``fmt``: 0 = fp32 NHWC; 1 = "split32" (same bytes: per 32 channels, 32 binary16 hi parts then
+        32 binary16 lo parts; value = hi + lo) — the operand image of the fp16x3 conv kernel."""
         assert buf.dim() == 4 and buf.dtype == torch.float32 and buf.is_contiguous()
-        self.buf, self.c0 = buf, c0
+        self.buf, self.c0, self.fmt = buf, c0, fmt
         self.c = buf.shape[3] - c0 if c is None else c
         assert 0 <= c0 and c0 + self.c <= buf.shape[3]
+        if fmt == 1:
+            assert c0 % 32 == 0 and self.c % 32 == 0 and buf.shape[3] % 32 == 0, "split32 views are 32-channel aligned"
 
     @staticmethod
-    def empty(n, h, w, c, device):
-        return Act(torch.empty((n, h, w, c), dtype=torch.float32, device=device))
+    def empty(n, h, w, c, device, fmt: int = 0):
+        return Act(torch.empty((n, h, w, c), dtype=torch.float32, device=device), fmt=fmt)
 
     @property
     def n(self): return self.buf.shape[0]
@@ -47,14 +51,17 @@ class Act:
     def ld(self): return self.buf.shape[3]
 
     def slice(self, c0, c):
-        return Act(self.buf, self.c0 + c0, c)
+        return Act(self.buf, self.c0 + c0, c, self.fmt)
 
     def ptr(self):
         return N.ptr(self.buf, 4 * self.c0)
 
     def nchw(self) -> torch.Tensor:
-        """Copy out as an NCHW torch tensor (tests only)."""
-        return self.buf[..., self.c0:self.c0 + self.c].permute(0, 3, 1, 2).contiguous()
+        """Copy out as an fp32 NCHW torch tensor (tests only)."""
+        v = self.buf[..., self.c0:self.c0 + self.c].contiguous()
+        if self.fmt == 1:
+            v = split32_to_f32(Act(v, fmt=1)).buf
+        return v.permute(0, 3, 1, 2).contiguous()
 
 
 @dataclass
@@ -229,21 +236,27 @@ class ConvStats:
 def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1.0,
          alpha: float = 1.0, res1: Act | None = None, res1_pre: bool = True,
          res2: Act | None = None, alpha2: float = 1.0, in_up2: bool = False,
-         tile_n: int | None = None) -> Act:
-    """Launch one fused convolution.  ``act_slope``: 1 = identity, 0 = ReLU."""
+         tile_n: int | None = None, out_fmt: int = 0) -> Act:
+    """Launch one fused convolution.  ``act_slope``: 1 = identity, 0 = ReLU.  ``out_fmt`` selects the
+    format of a freshly allocated output (an explicit ``out`` view carries its own)."""
     assert x.c == pc.cin, f"conv expects {pc.cin} input channels, got {x.c}"
     in_h, in_w = (x.h * 2, x.w * 2) if in_up2 else (x.h, x.w)
     oh = (in_h + 2 * pc.pad - pc.kh) // pc.stride + 1
     ow = (in_w + 2 * pc.pad - pc.kw) // pc.stride + 1
     if out is None:
-        out = Act.empty(x.n, oh, ow, pc.cout, x.buf.device)
+        out = Act.empty(x.n, oh, ow, pc.cout, x.buf.device, out_fmt)
     assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, pc.cout), "conv: bad output view"
+    if (x.fmt or out.fmt or (res1 is not None and res1.fmt) or (res2 is not None and res2.fmt)) and pc.precision != 1:
+        raise ValueError("split32 tensors can only be used with filters packed for the fp16x3 path")
     m = x.n * oh * ow
     d = N.ConvDesc()
     d.in_, d.w, d.out = x.ptr(), N.ptr(pc.w), out.ptr()
     d.bias = N.ptr(pc.bias)
     d.wscale = N.ptr(pc.wscale)
     d.precision = pc.precision
+    d.in_fmt, d.out_fmt = x.fmt, out.fmt
+    d.res1_fmt = res1.fmt if res1 is not None else 0
+    d.res2_fmt = res2.fmt if res2 is not None else 0
     d.res1 = res1.ptr() if res1 is not None else None
     d.res2 = res2.ptr() if res2 is not None else None
     d.n, d.in_h, d.in_w = x.n, in_h, in_w
@@ -265,7 +278,7 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
             d.tile_n = t
             N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
         key = (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, m, int(in_up2), res1 is not None, res2 is not None,
-               pc.precision)
+               pc.precision, x.fmt, out.fmt)
         d.tile_n = Autotune.pick(key, [64, 128], _launch)
     timing = ConvStats.timing
     if timing is not None:
@@ -309,7 +322,21 @@ def f32nchw_to_nhwc4(images: torch.Tensor, sub=(0.0, 0.0, 0.0), div: float = 1.0
 def maxpool3x3s2(x: Act) -> Act:
     assert x.c0 == 0 and x.c == x.ld
     oh, ow = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1
-    out = Act.empty(x.n, oh, ow, x.c, x.buf.device)
-    N.check(N.lib().fcp_maxpool3x3s2_nhwc_f32(x.ptr(), out.ptr(), x.n, x.h, x.w, x.c, oh, ow,
-                                              N.stream_ptr()), "fcp_maxpool3x3s2_nhwc_f32")
+    out = Act.empty(x.n, oh, ow, x.c, x.buf.device, x.fmt)
+    fn = N.lib().fcp_maxpool3x3s2_split32 if x.fmt == 1 else N.lib().fcp_maxpool3x3s2_nhwc_f32
+    N.check(fn(x.ptr(), out.ptr(), x.n, x.h, x.w, x.c, oh, ow, N.stream_ptr()), "fcp_maxpool3x3s2")
+    return out
+
+
+def f32_to_split32(x: Act) -> Act:
+    assert x.fmt == 0 and x.c0 == 0 and x.c == x.ld and x.c % 32 == 0
+    out = Act.empty(x.n, x.h, x.w, x.c, x.buf.device, 1)
+    N.check(N.lib().fcp_f32_to_split32(x.ptr(), out.ptr(), x.n * x.h * x.w, x.c, N.stream_ptr()), "fcp_f32_to_split32")
+    return out
+
+
+def split32_to_f32(x: Act) -> Act:
+    assert x.fmt == 1 and x.c0 == 0 and x.c == x.ld
+    out = Act.empty(x.n, x.h, x.w, x.c, x.buf.device, 0)
+    N.check(N.lib().fcp_split32_to_f32(x.ptr(), out.ptr(), x.n * x.h * x.w, x.c, N.stream_ptr()), "fcp_split32_to_f32")
     return out

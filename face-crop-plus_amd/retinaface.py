@@ -34,6 +34,7 @@ class RetinaFace:
         self.variance = [0.1, 0.2]
         self.device = None
         self._p = None
+        self.precision = 0
 
     # ------------------------------------------------------------------ load
     def load(self, device: str | torch.device = "cuda:0", weights=None, precision=None):
@@ -102,29 +103,32 @@ class RetinaFace:
     def forward_heads(self, x4: E.Act):
         """NHWC4 (RGB - mean) -> three fused head maps (n, h/8|16|32, w/.., 32)."""
         p = self._p
-        x = E.conv(p["stem"], x4, act_slope=0.0)
+        # fp16x3 path: activations between convs live in the "split32" format (hi/lo binary16 planes per 32
+        # channels, same bytes as fp32) so every consumer conv copies its operand instead of converting it
+        f = 1 if self.precision == 1 else 0
+        x = E.conv(p["stem"], x4, act_slope=0.0, out_fmt=f)
         x = E.maxpool3x3s2(x)
         feats = []
         for blk in p["blocks"]:
-            o = E.conv(blk["c1"], x, act_slope=0.0)
-            o = E.conv(blk["c2"], o, act_slope=0.0)
-            idt = x if blk["ds"] is None else E.conv(blk["ds"], x)
-            x = E.conv(blk["c3"], o, act_slope=0.0, res1=idt, res1_pre=True)
+            o = E.conv(blk["c1"], x, act_slope=0.0, out_fmt=f)
+            o = E.conv(blk["c2"], o, act_slope=0.0, out_fmt=f)
+            idt = x if blk["ds"] is None else E.conv(blk["ds"], x, out_fmt=f)
+            x = E.conv(blk["c3"], o, act_slope=0.0, res1=idt, res1_pre=True, out_fmt=f)
             if blk["feat"]:
                 feats.append(x)
         # FPN (_layers.py:127-145): LeakyReLU slope 0 == ReLU for 256 channels
-        o3 = E.conv(p["fpn.output3"], feats[2], act_slope=0.0)
-        o2 = E.conv(p["fpn.output2"], feats[1], act_slope=0.0, res1=o3, res1_pre=False)
-        o2 = E.conv(p["fpn.merge2"], o2, act_slope=0.0)
-        o1 = E.conv(p["fpn.output1"], feats[0], act_slope=0.0, res1=o2, res1_pre=False)
-        o1 = E.conv(p["fpn.merge1"], o1, act_slope=0.0)
+        o3 = E.conv(p["fpn.output3"], feats[2], act_slope=0.0, out_fmt=f)
+        o2 = E.conv(p["fpn.output2"], feats[1], act_slope=0.0, res1=o3, res1_pre=False, out_fmt=f)
+        o2 = E.conv(p["fpn.merge2"], o2, act_slope=0.0, out_fmt=f)
+        o1 = E.conv(p["fpn.output1"], feats[0], act_slope=0.0, res1=o2, res1_pre=False, out_fmt=f)
+        o1 = E.conv(p["fpn.merge1"], o1, act_slope=0.0, out_fmt=f)
         heads = []
-        for k, f in zip((1, 2, 3), (o1, o2, o3)):
-            s = E.Act.empty(f.n, f.h, f.w, 384, f.buf.device)
-            E.conv(p[f"ssh{k}.ab"], f, s.slice(0, 192), act_slope=0.0)
+        for k, ft in zip((1, 2, 3), (o1, o2, o3)):
+            s = E.Act.empty(ft.n, ft.h, ft.w, 384, ft.buf.device, f)
+            E.conv(p[f"ssh{k}.ab"], ft, s.slice(0, 192), act_slope=0.0)
             E.conv(p[f"ssh{k}.cd"], s.slice(0, 64), s.slice(256, 128), act_slope=0.0)
             E.conv(p[f"ssh{k}.e"], s.slice(320, 64), s.slice(192, 64), act_slope=0.0)
-            heads.append(E.conv(p[f"head{k}"], s.slice(64, 256)))
+            heads.append(E.conv(p[f"head{k}"], s.slice(64, 256)))      # fp32 out: the decode kernel reads it
         return heads
 
     # ---------------------------------------------------------------- detect

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 2
+#define FCP_ABI_VERSION 3
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -88,6 +88,13 @@ typedef struct fcp_conv_desc {
   float act_slope, alpha, alpha2;
   int32_t res1_pre, res1_ld, res1_h, res1_w, res2_ld;
   int32_t precision;  /* 0 = fp32 exact, 1 = fp16x3 split (filter packed accordingly) */
+  /* Activation tensor formats (precision 1 only): 0 = fp32 NHWC; 1 = "split32": same bytes per
+   * element and the same strides, but every group of 32 channels of a pixel is stored as 32 binary16
+   * hi parts followed by 32 binary16 lo parts (value = hi + lo, ~22 significant bits).  A K slice of
+   * a split32 tensor is byte-for-byte the kernel's LDS operand image, so the consumer conv copies it
+   * instead of converting; producers convert once in their epilogue.  Views must start on a
+   * 32-channel group and in_ld / out_ld / res*_ld must be multiples of 32. */
+  int32_t in_fmt, out_fmt, res1_fmt, res2_fmt;
 } fcp_conv_desc;
 
 int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);
@@ -108,6 +115,12 @@ int fcp_f32nchw_to_nhwc4_f32(const float* in, float* out, int n, int h, int w,
  * _layers.py:247).  c % 4 == 0. */
 int fcp_maxpool3x3s2_nhwc_f32(const float* in, float* out, int n, int h, int w, int c,
                               int out_h, int out_w, fcp_stream_t stream);
+/* Same on split32 tensors (c % 32 == 0); the maximum is exact (hi + lo decodes exactly). */
+int fcp_maxpool3x3s2_split32(const float* in, float* out, int n, int h, int w, int c,
+                             int out_h, int out_w, fcp_stream_t stream);
+/* Format converters between fp32 NHWC and split32 (npix pixels of c channels, c % 32 == 0). */
+int fcp_f32_to_split32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream);
+int fcp_split32_to_f32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * RetinaFace post-processing.

@@ -148,3 +148,61 @@ def test_maxpool(device):
     ref = F.max_pool2d(x, 3, 2, 1)
     out = E.maxpool3x3s2(E.Act(_nhwc(x, device))).nchw().cpu()
     assert torch.equal(out, ref)
+
+
+def test_split32_roundtrip_and_maxpool(device):
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 64, 21, 19, generator=g) * 30
+    a = E.Act(_nhwc(x, device))
+    sp = E.f32_to_split32(a)
+    back = sp.nchw().cpu()
+    assert (back - x).abs().max().item() <= 2.0 ** -20 * x.abs().max().item()
+    # idempotent: re-encoding a decoded tensor reproduces the same values (bytes may differ in the sign of a zero lo)
+    again = E.f32_to_split32(E.split32_to_f32(sp))
+    assert torch.equal(again.nchw(), sp.nchw())
+    mp = E.maxpool3x3s2(sp)
+    assert mp.fmt == 1 and torch.equal(mp.nchw().cpu(), F.max_pool2d(back, 3, 2, 1))
+
+
+@pytest.mark.parametrize("k,stride,cin,cout", [(1, 1, 64, 256), (3, 1, 128, 128), (3, 2, 64, 64), (1, 2, 256, 512)])
+def test_conv_split32_in_out_with_residual(k, stride, cin, cout, device, precision):
+    """split32 activations end to end: split input, split residual, split output (fp16x3 path only)."""
+    if precision != "f16x3":
+        pytest.skip("split32 tensors exist only on the fp16x3 path")
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(k * 100 + cin)
+    n, h, w = 2, 18, 22
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, stride, k // 2)
+    res = torch.randn(*ref.shape, generator=g)
+    ref = F.relu(ref + res)
+    pc = E.pack_conv(wt, b, None, stride, k // 2, device)
+    xs = E.f32_to_split32(E.Act(_nhwc(x, device)))
+    rs = E.f32_to_split32(E.Act(_nhwc(res, device)))
+    for tile_n in (64, 128):
+        out = E.conv(pc, xs, act_slope=0.0, res1=rs, res1_pre=True, out_fmt=1, tile_n=tile_n)
+        assert out.fmt == 1
+        assert (out.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+        # mixed: split input, fp32 residual and output
+        out2 = E.conv(pc, xs, act_slope=0.0, res1=E.Act(_nhwc(res, device)), res1_pre=True, tile_n=tile_n)
+        assert out2.fmt == 0 and (out2.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+
+
+def test_conv_split32_channel_slices(device, precision):
+    """SSH-style: read a 32-aligned channel slice of a split32 buffer, write another slice of it."""
+    if precision != "f16x3":
+        pytest.skip("split32 tensors exist only on the fp16x3 path")
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(11)
+    feat = torch.randn(1, 384, 14, 17, generator=g)
+    buf = E.f32_to_split32(E.Act(_nhwc(feat, device)))
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    b = torch.randn(128, generator=g)
+    ref = F.relu(F.conv2d(feat[:, :64], w, b, 1, 1))
+    E.conv(E.pack_conv(w, b, None, 1, 1, device), buf.slice(0, 64), buf.slice(256, 128), act_slope=0.0)
+    full = buf.nchw().cpu()
+    assert (full[:, 256:384] - ref).abs().max().item() <= _tol(ref)
+    assert (full[:, :256] - feat[:, :256]).abs().max().item() <= 2.0 ** -20 * feat.abs().max().item()   # untouched
