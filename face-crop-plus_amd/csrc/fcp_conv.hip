@@ -348,6 +348,9 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
     FCP_REQUIRE(d->wscale != nullptr, "conv: precision 1 needs wscale");
     k.in_bytes = (unsigned)in_bytes;
     k.w_bytes = (unsigned)w_bytes;
+    // split32 activations: both operands are pure byte copies -> LDS-DMA kernel
+    static const int dma_env = getenv("FCP_CONV_DMA") ? atoi(getenv("FCP_CONV_DMA")) : 2;   // 0 off, 2 / 3 = LDS stages
+    if (k.in_fmt == 1 && !d->cin4 && dma_env) return launch_f16x3_dma(k, d->tile_n, dma_env, s);
     return launch_f16x3(k, d->tile_n, d->cin4 != 0, s);
   }
   k.in_bytes = buf ? (unsigned)in_bytes : 0u;
