@@ -27,6 +27,7 @@ class RRDBNet:
         self.min_face_factor = min_face_factor
         self.device = None
         self._p = None
+        self.precision = 0
 
     def load(self, device="cuda:0", weights=None, precision=None):
         device = torch.device(device)
@@ -45,14 +46,16 @@ class RRDBNet:
             p["trunk"] = [[[pc(f"RRDB_trunk.{t}.RDB{r}.conv{c}") for c in range(1, 6)] for r in (1, 2, 3)]
                           for t in range(self.NUM_BLOCKS)]
             self._p = p
+        self.precision = E.resolve_precision(precision)
         return self
 
     def forward(self, x4: E.Act) -> E.Act:
         """NHWC4 image in [0,1] (n,h,w,4) -> (n,4h,4w,4) with the RGB output in channels 0..2."""
         p = self._p
         n, h, w, dev = x4.n, x4.h, x4.w, x4.buf.device
-        bufs = [E.Act.empty(n, h, w, 192, dev) for _ in range(3)]     # one dense-block concat buffer per RDB
-        fea0 = E.conv(p["conv_first"], x4)                             # kept for the trunk residual
+        f = 1 if self.precision == 1 else 0     # fp16x3: trunk activations in split32 (operands are DMA copies)
+        bufs = [E.Act.empty(n, h, w, 192, dev, f) for _ in range(3)]  # one dense-block concat buffer per RDB
+        fea0 = E.conv(p["conv_first"], x4, out_fmt=f)                  # kept for the trunk residual
         E.conv(p["conv_first"], x4, bufs[0].slice(0, 64))              # and as x of the first RDB
         for t, rrdb in enumerate(p["trunk"]):
             for r, convs in enumerate(rrdb):
@@ -65,10 +68,10 @@ class RRDBNet:
                 else:                                                  # (x5*0.2 + x)*0.2 + x_rrdb
                     E.conv(convs[4], b, nxt.slice(0, 64), alpha=0.2, res1=b.slice(0, 64), res1_pre=False,
                            res2=bufs[0].slice(0, 64), alpha2=0.2)
-        fea = E.conv(p["trunk_conv"], bufs[0].slice(0, 64), res1=fea0, res1_pre=False)
+        fea = E.conv(p["trunk_conv"], bufs[0].slice(0, 64), res1=fea0, res1_pre=False, out_fmt=f)
         del bufs
-        fea = E.conv(p["upconv1"], fea, act_slope=0.2, in_up2=True)
-        fea = E.conv(p["upconv2"], fea, act_slope=0.2, in_up2=True)
+        fea = E.conv(p["upconv1"], fea, act_slope=0.2, in_up2=True, out_fmt=f)
+        fea = E.conv(p["upconv2"], fea, act_slope=0.2, in_up2=True)     # fp32 out: the x4 tail runs the fp32 kernel
         fea = E.conv(p["HRconv"], fea, act_slope=0.2)
         out = E.Act.empty(n, 4 * h, 4 * w, 4, dev)
         E.conv(p["conv_last"], fea, out.slice(0, 3))
