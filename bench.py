@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
                     help="conv arithmetic: split-fp16 MFMA (fp32-equivalent accuracy) or exact fp32 MFMA")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batch is split over")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
@@ -75,18 +77,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from face_crop_plus_amd import weights, align, engine as E
     from face_crop_plus_amd.retinaface import RetinaFace
 
     sd = weights.generate_state_dict("retinaface")
-    if world > 1:
+    if dist is not None:
         from face_crop_plus_amd.dist import broadcast_state_dict
-        sd = broadcast_state_dict(sd, dev)
+        sd = broadcast_state_dict(sd, dev)        # rank 0's weights -> all ranks, one flat RCCL broadcast
     det = RetinaFace(args.strategy, 0.6).load(dev, sd, args.precision)
     from face_crop_plus_amd.cropper import landmarks_target
     tgt = torch.from_numpy(landmarks_target((args.out_size, args.out_size), 0.65)).to(dev)

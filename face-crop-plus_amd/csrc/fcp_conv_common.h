@@ -228,11 +228,44 @@ __device__ __forceinline__ void load8(const float* base, long pix, int ld, int c
   }
 }
 
+// Residual tile of a workgroup, fetched at kernel start so its HBM latency hides under the main loop
+// (the 1x1 "c3" convs of the bottlenecks have 2-8 K slices only: their cost is the epilogue's traffic).
+template <int BN>
+struct ResPrefetch {
+  static constexpr int CPR = BN / 8, RPP = 256 / CPR, PASSES = BM / RPP;
+  u32x4_t a[PASSES], b[PASSES];   // split32: hi, lo chunks; fp32: channels c..c+3, c+4..c+7
+  bool valid;
+};
+
+template <int BN>
+__device__ __forceinline__ void prefetch_res1(const ConvK& p, int tile_m, int tile_n, int tid, ResPrefetch<BN>& r) {
+  constexpr int CPR = BN / 8, RPP = 256 / CPR, PASSES = BM / RPP;
+  const int co = tile_n * BN + (tid % CPR) * 8;
+  const long m0 = (long)tile_m * BM + tid / CPR;
+  r.valid = p.res1 != nullptr && !p.res1_resize && co < p.cout;
+  if (!r.valid) return;
+#pragma unroll
+  for (int g = 0; g < PASSES; ++g) {
+    const long m = m0 + (long)g * RPP;
+    if (m < p.M) {
+      if (p.res1_fmt == 1) {
+        const char* pb = reinterpret_cast<const char*>(p.res1) + m * p.res1_ld * 4 + split_chan_off(co);
+        r.a[g] = *reinterpret_cast<const u32x4_t*>(pb);
+        r.b[g] = *reinterpret_cast<const u32x4_t*>(pb + 64);
+      } else {
+        r.a[g] = *reinterpret_cast<const u32x4_t*>(p.res1 + m * p.res1_ld + co);
+        r.b[g] = *reinterpret_cast<const u32x4_t*>(p.res1 + m * p.res1_ld + co + 4);
+      }
+    }
+  }
+}
+
 // Epilogue for 8-channel granularity: used whenever the output or a residual is in split32 format
 // (cout % 8 == 0, all tensors 16-byte aligned).  Same arithmetic as conv_epilogue.
 template <int BN, int TM, int TN, int WTM, int WTN>
 __device__ __forceinline__ void conv_epilogue8(const ConvK& p, f32x16 (&acc)[TM][TN], float* smem, int tile_m,
-                                               int tile_n, int tid, int lane, int wm, int wn, int hw) {
+                                               int tile_n, int tid, int lane, int wm, int wn, int hw,
+                                               const ResPrefetch<BN>* pre = nullptr) {
   constexpr int CPR = BN / 8;
   constexpr int RPP = 256 / CPR;
   constexpr int PASSES = BM / RPP;
@@ -261,7 +294,8 @@ __device__ __forceinline__ void conv_epilogue8(const ConvK& p, f32x16 (&acc)[TM]
     bias8[e] = p.bias != nullptr ? p.bias[co + e] : 0.f;
     ws8[e] = p.wscale != nullptr ? p.wscale[co + e] : 1.f;
   }
-#pragma unroll 2
+  const bool use_pre = pre != nullptr && pre->valid;
+#pragma unroll
   for (int g = 0; g < PASSES; ++g) {
     const int row = crow + g * RPP;
     const long m = m0 + (long)g * RPP;
@@ -272,7 +306,14 @@ __device__ __forceinline__ void conv_epilogue8(const ConvK& p, f32x16 (&acc)[TM]
       const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * BN + ccol + 4);
       v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
     }
-    if (p.res1 != nullptr) {
+    if (use_pre) {
+      if (p.res1_fmt == 1) {
+        join8(pre->a[g], pre->b[g], r1);
+      } else {
+        const f32x4 fa = __builtin_bit_cast(f32x4, pre->a[g]), fb = __builtin_bit_cast(f32x4, pre->b[g]);
+        r1[0] = fa[0]; r1[1] = fa[1]; r1[2] = fa[2]; r1[3] = fa[3]; r1[4] = fb[0]; r1[5] = fb[1]; r1[6] = fb[2]; r1[7] = fb[3];
+      }
+    } else if (p.res1 != nullptr) {
       long rpix = m;
       if (p.res1_resize) {
         const int ni = (int)(m / hw);

@@ -120,6 +120,12 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : 3)) conv_igemm_f16x3_dma
                                                (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
   };
 
+  // residual tile first: its HBM round trip overlaps the whole main loop
+  ResPrefetch<BN> rpre;
+  rpre.valid = false;
+  const bool ep8 = (p.out_fmt | p.res1_fmt | p.res2_fmt) != 0;
+  if (ep8) prefetch_res1<BN>(p, tile_m, tile_n, tid, rpre);
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -199,8 +205,8 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : 3)) conv_igemm_f16x3_dma
     if (++stage >= NST) stage = 0;
   }
 
-  if (p.out_fmt | p.res1_fmt | p.res2_fmt)
-    conv_epilogue8<BN, TM, TN, WTM, WTN>(p, acc, smem, tile_m, tile_n, tid, lane, wm, wn, hw);
+  if (ep8)
+    conv_epilogue8<BN, TM, TN, WTM, WTN>(p, acc, smem, tile_m, tile_n, tid, lane, wm, wn, hw, &rpre);
   else
     conv_epilogue<BN, TM, TN, WTM, WTN>(p, acc, smem, tile_m, tile_n, tid, lane, wm, wn, hw);
 }
