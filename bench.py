@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
                     help="conv arithmetic: split-fp16 MFMA (fp32-equivalent accuracy) or exact fp32 MFMA")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the detection step from a captured HIP graph (small, launch-bound batches)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batch is split over")
@@ -110,8 +112,16 @@ def main():
         par = BiSeNet({"glasses": [6]}, {"eyes": [4, 5]}, 32).load(dev, weights.generate_state_dict("bisenet"),
                                                                    args.precision)
 
+    graphed = det.graphed(args.batch, args.size, args.size) if args.graph else None
+
     def step_chunk(imgs, count):
-        res = det.detect(imgs, max_faces=imgs.shape[0] if args.strategy != "all" else None)
+        nonlocal graphed
+        if graphed is not None:
+            graphed[0].copy_(imgs)
+            graphed[2].replay()
+            res = graphed[1]
+        else:
+            res = det.detect(imgs, max_faces=imgs.shape[0] if args.strategy != "all" else None)
         if enh is not None:
             imgs = imgs.clone()                      # enhancement rewrites the batch in place
             which = list(range(imgs.shape[0]))
@@ -181,7 +191,9 @@ def main():
     roofline = None
     if rank == 0:
         E.ConvStats.timing = []
+        graphed_saved, graphed = graphed, None      # per-launch events need the eager launches
         step(False)
+        graphed = graphed_saved
         torch.cuda.synchronize()
         conv_ms = sum(a.elapsed_time(b) for a, b, _ in E.ConvStats.timing)
         conv_flops = sum(f for _, _, f in E.ConvStats.timing)

@@ -183,6 +183,38 @@ class RetinaFace:
                    heads=heads, dense=dense, max_faces=max_faces)
         return out
 
+    # ----------------------------------------------------------------- graphs
+    def graphed(self, n: int, h: int, w: int, paddings: torch.Tensor | None = None):
+        """Capture one detection step for a fixed (n,h,w) uint8 batch into a HIP graph.
+
+        Small batches are launch-bound (~75 kernel launches from Python per step); replaying a
+        captured graph removes the host from the loop.  Returns ``(static_images, result, graph)``:
+        write the batch into ``static_images``, call ``graph.replay()``, read ``result`` (the dict
+        ``detect`` returns; all tensors are static).  Only for strategies with a bounded face count
+        ("best" / "largest"), which need no host read-back inside the step."""
+        if self.strategy == "all":
+            raise ValueError('graph capture needs a bounded face count: strategy "best" or "largest"')
+        key = (n, h, w, None if paddings is None else tuple(paddings.flatten().tolist()))
+        cache = self.__dict__.setdefault("_graphs", {})
+        if key in cache:
+            return cache[key]
+        with torch.cuda.device(self.device):
+            static = torch.zeros((n, h, w, 3), dtype=torch.uint8, device=self.device)
+            prev, E.Autotune.enabled = E.Autotune.enabled, True
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):              # warm-up: lazy module loads, tile autotuning, allocator
+                    self.detect(static, paddings=paddings, max_faces=n)
+            torch.cuda.current_stream().wait_stream(side)
+            E.Autotune.enabled = False
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                res = self.detect(static, paddings=paddings, max_faces=n)
+            E.Autotune.enabled = prev
+        cache[key] = (static, res, graph)
+        return cache[key]
+
     # --------------------------------------------------------------- predict
     @torch.no_grad()
     def predict(self, images: torch.Tensor):

@@ -81,3 +81,23 @@ def test_cpu_device_is_refused(sd):
     from face_crop_plus_amd.retinaface import RetinaFace
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         RetinaFace().load("cpu", sd)
+
+
+def test_graph_replay_matches_eager(sd, device):
+    """HIP-graph replay of the detection step gives bit-identical landmarks, batch after batch."""
+    from face_crop_plus_amd.retinaface import RetinaFace
+    det = RetinaFace("largest", 0.6).load(device, sd)
+    static, res, graph = det.graphed(2, 128, 160)
+    g = torch.Generator().manual_seed(9)
+    for _ in range(3):
+        imgs = torch.randint(0, 256, (2, 128, 160, 3), generator=g, dtype=torch.uint8).to(device)
+        eager = det.detect(imgs, max_faces=2)
+        static.copy_(imgs)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(res["face_offset"], eager["face_offset"])
+        nf = int(eager["face_offset"][-1].item())
+        assert torch.equal(res["landmarks"][:nf], eager["landmarks"][:nf])
+        assert torch.equal(res["img_idx"][:nf], eager["img_idx"][:nf])
+    with pytest.raises(ValueError):
+        RetinaFace("all", 0.6).load(device, sd).graphed(1, 64, 64)
