@@ -339,6 +339,7 @@ __device__ __forceinline__ void conv_epilogue8(const ConvK& p, f32x16 (&acc)[TM]
       if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
       v[e] = x;
     }
+    if (p.ablate & 64) continue;   // profiling only: no output stores
     if (p.out_fmt == 1) {
       u32x4_t hi, lo;
       split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);

@@ -91,3 +91,43 @@ def test_crop_align_numpy_signature(device):
     ragged = c.crop_align([imgs[0], imgs[1][:50]], None, [0, 1], lm[[0, 2]])
     assert ragged.shape == (2, 32, 32, 3)
     assert np.array_equal(ragged[0], out[0])
+
+
+def test_nonsquare_resize_all_strategy_with_parse(tmp_path, device):
+    """configs[4]-style shapes in miniature: wide images letter-boxed into a non-square batch
+    (top/bottom padding, utils.py:322-326), strategy "all", parsing on; crops equal a per-face warp."""
+    from PIL import Image
+    from face_crop_plus_amd import Cropper, weights, utils
+    from oracle import retinaface_ref as R, align_ref as A
+    src = tmp_path / "wide"
+    src.mkdir()
+    rng = np.random.default_rng(11)
+    for i in range(3):
+        Image.fromarray(rng.integers(0, 256, (135, 240, 3), dtype=np.uint8)).save(src / f"w{i}.png")
+    sd = weights.generate_state_dict("retinaface")
+    out = tmp_path / "out"
+    c = Cropper(output_size=(48, 64), resize_size=(192, 128), strategy="all", det_threshold=0.6, batch_size=3,
+                mask_groups={"hair": [17]}, device="cuda:0", weights={"retinaface": sd, "bisenet": "generated"})
+    c.process_dir(str(src), str(out), desc=None)
+    names = sorted(os.listdir(src))
+    imgs, _ = utils.read_images(names, str(src))
+    batch, _, pads = utils.as_batch(imgs, (192, 128))
+    assert batch.shape == (3, 128, 192, 3) and pads[0].tolist() == [10, 10, 0, 0]
+    lm, idx = R.predict(torch.from_numpy(batch).permute(0, 3, 1, 2).float(), sd, "all", 0.6)
+    assert len(idx) > 3                                             # several faces per image
+    lm = lm - pads[idx][:, None, [2, 0]]
+    crops = A.crop_align(batch, pads, idx, lm, A.landmarks_target((48, 64), 0.65), (48, 64), "constant")
+    assert crops.shape[1:] == (64, 48, 3)                           # (h, w) from output_size=(w, h)
+    written = sorted(os.listdir(out / "hair"))
+    per_file = {n: sum(1 for i in idx if names[i] == n) for n in names}
+    exp_names = sorted(f"{os.path.splitext(n)[0]}_{k}.png" for n in names for k in range(per_file[n]))
+    assert set(written) <= set(exp_names) and len(written) > 0
+    k_of = {}
+    for k, i in enumerate(idx):
+        k_of.setdefault(i, []).append(k)
+    for fn in written:
+        stem, j = fn[:-4].rsplit("_", 1)
+        face = k_of[names.index(stem + ".png")][int(j)]
+        got = np.asarray(Image.open(out / "hair" / fn).convert("RGB"))
+        assert got.shape == (64, 48, 3) and (got != crops[face]).mean() < 0.01
+    assert sorted(os.listdir(out / "hair_mask")) == written
