@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_f32p = C.c_void_p
 _lib = None
@@ -57,6 +57,7 @@ SIGNATURES = {
     "fcp_label_mask_u8": [_P, _L, C.c_uint32, _P, _P],
     "fcp_bicubic_down4_u8": [_P, _I, _I, _I, _P, _P],
     "fcp_warp_affine_u8": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "fcp_build_batch_u8": [_P, _L, _P, _P, _I, _I, _I, _I, _P, _P],
 }
 EXPORTS = ["fcp_abi_version", "fcp_last_error", "fcp_retina_nms_workspace_bytes"] + list(SIGNATURES)
 

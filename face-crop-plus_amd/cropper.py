@@ -15,7 +15,8 @@ import numpy as np
 import torch
 
 from . import align
-from .utils import (as_batch, get_ldm_slices, parse_landmarks_file, read_images, write_image)
+from .batch import build_batch
+from .utils import get_ldm_slices, parse_landmarks_file, read_images, write_image
 
 
 def landmarks_target(output_size, face_factor):
@@ -210,8 +211,7 @@ class Cropper:
                     indices_ldm.extend(indices_i.tolist())
                 landmarks = self.landmarks[0][indices_ldm]
             else:
-                batch, _, paddings = as_batch(images, self.resize_size)
-                images_dev = torch.from_numpy(batch).to(self.device)
+                images_dev, _, paddings = build_batch(images, self.resize_size, "constant", self.device)
                 lm_np, indices = self.det_model.predict(images_dev)
                 landmarks = lm_np - paddings[indices][:, None, [2, 0]].astype(np.float32) if len(indices) else lm_np
 

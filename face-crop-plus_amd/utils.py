@@ -1,9 +1,8 @@
 """Host utilities around the hot path (mirror of the reference's ``utils.py``
-surface that ``Cropper`` needs).  Image file I/O uses Pillow: OpenCV is not a
-dependency of this build.  ``as_batch`` is host glue here (SURVEY.md §8f-1
-"NEXT"): its resampling is Pillow's, *not* OpenCV's INTER_AREA / INTER_CUBIC
-bit-for-bit — the measured hot path starts from a batch that already has
-``resize_size``.
+surface that ``Cropper`` needs).  Image file decode / encode uses Pillow: OpenCV
+is not a dependency of this build.  ``as_batch`` runs on the
+GPU (``batch.py`` / ``csrc/fcp_batch.hip``: OpenCV's INTER_AREA / INTER_CUBIC
+uint8 arithmetic restated).
 """
 from __future__ import annotations
 
@@ -77,35 +76,14 @@ def read_images(file_names, input_dir):
     return images, np.array(file_names)[indices]
 
 
-def as_batch(images, size=512, padding_mode: str = "constant"):
-    """Aspect-preserving resize + centred padding to a common size (utils.py:273-342).
-    Returns (batch (N,H,W,3) uint8, unscales (N,), paddings (N,4) int64 [t,b,l,r])."""
-    from PIL import Image
-    size = (size, size) if isinstance(size, int) else tuple(size)
-    batch, unscales, paddings = [], [], []
-    for image in images:
-        h, w = image.shape[:2]
-        m = max(h, w)
-        resample = Image.BOX if m > max(size) else Image.BICUBIC
-        ratio_w, ratio_h = size[0] / w, size[1] / h
-        if ratio_w < ratio_h:
-            unscale = ratio_w
-            ww, hh = size[0], int(h * ratio_w)
-            padding = [(size[1] - hh) // 2, (size[1] - hh + 1) // 2, 0, 0]
-        else:
-            unscale = ratio_h
-            ww, hh = int(w * ratio_h), size[1]
-            padding = [0, 0, (size[0] - ww) // 2, (size[0] - ww + 1) // 2]
-        if (ww, hh) != (w, h):
-            image = np.asarray(Image.fromarray(image).resize((max(ww, 1), max(hh, 1)), resample), dtype=np.uint8)
-        t, b, l, r = padding
-        mode = {"constant": "constant", "replicate": "edge", "reflect": "symmetric", "wrap": "wrap",
-                "reflect_101": "reflect"}.get(padding_mode.lower(), "constant")
-        image = np.pad(image, ((t, b), (l, r), (0, 0)), mode=mode)
-        batch.append(image)
-        unscales.append(np.array(unscale))
-        paddings.append(np.array(padding))
-    return np.stack(batch), np.stack(unscales), np.stack(paddings)
+def as_batch(images, size=512, padding_mode: str = "constant", device="cuda:0"):
+    """Aspect-preserving resize + centred padding to a common size (utils.py:273-342), reference
+    signature: returns (batch (N,H,W,3) uint8 numpy, unscales (N,), paddings (N,4) int64 [t,b,l,r]).
+    The pixels are produced on the GPU by ``batch.build_batch`` (which ``Cropper`` calls directly to
+    keep the batch on the device); there is no CPU resampler in this build."""
+    from .batch import build_batch
+    batch, unscales, paddings = build_batch(images, size, padding_mode, device)
+    return batch.cpu().numpy(), unscales, paddings
 
 
 def write_image(path: str, image: np.ndarray):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 3
+#define FCP_ABI_VERSION 4
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -243,6 +243,30 @@ int fcp_label_mask_u8(const uint8_t* labels, int64_t total, uint32_t class_bits,
  * ------------------------------------------------------------------------ */
 int fcp_bicubic_down4_u8(const float* x4, int h, int w, int ld, uint8_t* out_rgb,
                          fcp_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Batch builder (utils.py:273-342, `as_batch`): cv2.resize (INTER_AREA when the
+ * image is larger than the batch, else INTER_CUBIC; uint8) of every image of a
+ * ragged list + cv2.copyMakeBorder into its slot of one (n,out_h,out_w,3) uint8
+ * batch, one launch.  The host computes the geometry of utils.py:316-331 and
+ * fills one item per image; the images are packed back to back (RGB, HWC) in
+ * one device blob.  items_host is validated here; items_dev is the caller's
+ * device copy of the same table.  border = cv2.BORDER_* code as for
+ * fcp_warp_affine_u8 (the reference always passes "constant", utils.py:276).
+ * ------------------------------------------------------------------------ */
+typedef struct fcp_batch_item {
+  int64_t src_off;    /* byte offset of the (sh,sw,3) image inside src_blob */
+  int32_t sh, sw;     /* source height, width */
+  int32_t dh, dw;     /* resized height, width (hh, ww of utils.py:322-331) */
+  int32_t top, left;  /* padding in front of the resized image (paddings[0], paddings[2]) */
+  int32_t interp;     /* 0 = cv2.INTER_CUBIC, 1 = cv2.INTER_AREA (decimation only) */
+  int32_t reserved;
+} fcp_batch_item;
+
+int fcp_build_batch_u8(const uint8_t* src_blob, int64_t blob_bytes,
+                       const fcp_batch_item* items_host, const fcp_batch_item* items_dev,
+                       int n, int out_h, int out_w, int border, uint8_t* out,
+                       fcp_stream_t stream);
 
 #ifdef __cplusplus
 }

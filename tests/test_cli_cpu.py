@@ -44,9 +44,17 @@ def test_host_utils(tmp_path):
     with pytest.warns(UserWarning):
         imgs, names = utils.read_images(["a.png", "broken.jpg", "b.png"], str(tmp_path))
     assert names.tolist() == ["a.png", "b.png"] and imgs[0].shape == (50, 80, 3)
-    batch, unscales, pads = utils.as_batch(imgs, (64, 64))
-    assert batch.shape == (2, 64, 64, 3) and batch.dtype == np.uint8
-    assert pads.tolist() == [[12, 12, 0, 0], [0, 0, 18, 18]]        # [t, b, l, r], utils.py:322-331
+    from face_crop_plus_amd.batch import batch_geometry
+    from oracle import batch_ref
+    for im in imgs + [np.zeros((2160, 3840, 3), np.uint8), np.zeros((64, 64, 3), np.uint8)]:
+        h, w = im.shape[:2]
+        for size in ((64, 64), (512, 256), (1024, 1024)):
+            ww, hh, pad, unscale, interp = batch_geometry(h, w, size)
+            assert (ww, hh, pad, unscale, ("cubic", "area")[interp]) == batch_ref.geometry(h, w, size)
+    assert batch_geometry(50, 80, (64, 64))[2] == [12, 12, 0, 0]   # [t, b, l, r], utils.py:322-331
+    assert batch_geometry(90, 40, (64, 64))[2] == [0, 0, 18, 18]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):     # the pixels come from the GPU builder only
+        utils.as_batch(imgs, (64, 64), device="cpu")
     assert utils.get_ldm_slices(5, 68)[0] == slice(36, 42)
     with pytest.raises(ValueError):
         utils.get_ldm_slices(5, 7)

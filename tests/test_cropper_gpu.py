@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import retinaface_ref as R, align_ref as A
+from oracle import retinaface_ref as R, align_ref as A, batch_ref as B
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +35,7 @@ def test_process_dir_matches_oracle(image_dir, tmp_path, device):
     # oracle: same batch building, CPU detector + OpenCV-restated crop
     names = sorted(f for f in os.listdir(image_dir) if f != "broken.png")
     imgs, _ = utils.read_images(names, image_dir)
-    batch, _, pads = utils.as_batch(imgs, (160, 160))
+    batch, _, pads = B.as_batch(imgs, (160, 160))           # oracle cv2.resize + pad
     lm, idx = R.predict(torch.from_numpy(batch).permute(0, 3, 1, 2).float(), sd, "largest", 0.6)
     lm = lm - pads[idx][:, None, [2, 0]]
     crops = A.crop_align(batch, pads, idx, lm, A.landmarks_target((64, 64), 0.65), (64, 64), "constant")
@@ -98,7 +98,7 @@ def test_nonsquare_resize_all_strategy_with_parse(tmp_path, device):
     (top/bottom padding, utils.py:322-326), strategy "all", parsing on; crops equal a per-face warp."""
     from PIL import Image
     from face_crop_plus_amd import Cropper, weights, utils
-    from oracle import retinaface_ref as R, align_ref as A
+    from oracle import retinaface_ref as R, align_ref as A, batch_ref as B
     src = tmp_path / "wide"
     src.mkdir()
     rng = np.random.default_rng(11)
@@ -106,14 +106,14 @@ def test_nonsquare_resize_all_strategy_with_parse(tmp_path, device):
         Image.fromarray(rng.integers(0, 256, (135, 240, 3), dtype=np.uint8)).save(src / f"w{i}.png")
     sd = weights.generate_state_dict("retinaface")
     out = tmp_path / "out"
-    c = Cropper(output_size=(48, 64), resize_size=(192, 128), strategy="all", det_threshold=0.6, batch_size=3,
+    c = Cropper(output_size=(48, 64), resize_size=(192, 128), strategy="all", det_threshold=0.55, batch_size=3,
                 mask_groups={"hair": [17]}, device="cuda:0", weights={"retinaface": sd, "bisenet": "generated"})
     c.process_dir(str(src), str(out), desc=None)
     names = sorted(os.listdir(src))
     imgs, _ = utils.read_images(names, str(src))
-    batch, _, pads = utils.as_batch(imgs, (192, 128))
+    batch, _, pads = B.as_batch(imgs, (192, 128))
     assert batch.shape == (3, 128, 192, 3) and pads[0].tolist() == [10, 10, 0, 0]
-    lm, idx = R.predict(torch.from_numpy(batch).permute(0, 3, 1, 2).float(), sd, "all", 0.6)
+    lm, idx = R.predict(torch.from_numpy(batch).permute(0, 3, 1, 2).float(), sd, "all", 0.55)
     assert len(idx) > 3                                             # several faces per image
     lm = lm - pads[idx][:, None, [2, 0]]
     crops = A.crop_align(batch, pads, idx, lm, A.landmarks_target((48, 64), 0.65), (48, 64), "constant")
