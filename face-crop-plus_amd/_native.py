@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_f32p = C.c_void_p
 _lib = None
@@ -32,6 +32,7 @@ class ConvDesc(C.Structure):
         ("res1_pre", C.c_int32), ("res1_ld", C.c_int32), ("res1_h", C.c_int32),
         ("res1_w", C.c_int32), ("res2_ld", C.c_int32), ("precision", C.c_int32),
         ("in_fmt", C.c_int32), ("out_fmt", C.c_int32), ("res1_fmt", C.c_int32), ("res2_fmt", C.c_int32),
+        ("tile_m", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -41,8 +42,8 @@ SIGNATURES = {
     "fcp_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P],
     "fcp_u8_to_nhwc4_f32": [_P, _P, _L, C.POINTER(C.c_float), _F, _P],
     "fcp_f32nchw_to_nhwc4_f32": [_P, _P, _I, _I, _I, C.POINTER(C.c_float), _F, _P],
-    "fcp_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "fcp_maxpool3x3s2_split32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "fcp_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fcp_maxpool3x3s2_split32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "fcp_f32_to_split32": [_P, _P, _L, _I, _P],
     "fcp_split32_to_f32": [_P, _P, _L, _I, _P],
     "fcp_retina_decode": [_P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],

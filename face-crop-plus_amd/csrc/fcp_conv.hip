@@ -269,7 +269,13 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   FCP_REQUIRE(d != nullptr, "conv: null descriptor");
   FCP_REQUIRE(d->in && d->w && d->out, "conv: null tensor pointer");
   FCP_REQUIRE(d->n > 0 && d->in_h > 0 && d->in_w > 0 && d->cout > 0, "conv: bad sizes");
-  FCP_REQUIRE(d->tile_n == 32 || d->tile_n == 64 || d->tile_n == 128, "conv: tile_n must be 32/64/128");
+  const bool big = d->tile_m == 256;
+  FCP_REQUIRE(d->tile_m == 0 || d->tile_m == 128 || big, "conv: tile_m must be 0/128/256");
+  FCP_REQUIRE(d->tile_n == 32 || d->tile_n == 64 || d->tile_n == 128 || (big && d->tile_n == 256),
+              "conv: tile_n must be 32/64/128 (or 256 with tile_m 256)");
+  if (big)
+    FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && !d->in_up2 && d->cout % 8 == 0 && d->tile_n >= 128,
+                "conv: 256-row tiles need the fp16x3 path on a split32 input (no cin4 / in_up2), cout %% 8 == 0, tile_n 128/256");
   FCP_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->pad >= 0, "conv: bad filter geometry");
   FCP_REQUIRE(d->kh * d->kw <= 32 || d->cin4, "conv: at most 32 filter taps (kh*kw) outside cin4 mode");
   FCP_REQUIRE(d->in_ld % 4 == 0 && ((uintptr_t)d->in & 15) == 0, "conv: input must be 16-byte aligned, in_ld %% 4 == 0");
@@ -350,6 +356,10 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
     k.w_bytes = (unsigned)w_bytes;
     // split32 activations: both operands are pure byte copies -> LDS-DMA kernel
     static const int dma_env = getenv("FCP_CONV_DMA") ? atoi(getenv("FCP_CONV_DMA")) : 2;   // 0 off, 2 / 3 = LDS stages
+    if (big) {
+      k.w_bytes = (unsigned)((unsigned long)fcp_cdiv(d->cout, 128) * 128ul * k.wrow * 4ul);   // filters are padded to 128 rows
+      return launch_f16x3_big(k, d->tile_n, s);
+    }
     if (k.in_fmt == 1 && !d->cin4 && dma_env) return launch_f16x3_dma(k, d->tile_n, dma_env, s);
     return launch_f16x3(k, d->tile_n, d->cin4 != 0, s);
   }

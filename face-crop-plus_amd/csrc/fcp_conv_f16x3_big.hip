@@ -1,0 +1,339 @@
+// fp16x3 convolution, 256-row tiles, 8 waves, software-pipelined at half-slice granularity.
+//
+// Same operands and arithmetic as conv_igemm_f16x3_dma (split32 activations and offline-split
+// filters moved global -> LDS by `buffer_load ... lds`; al*bh + ah*bl + ah*bh on
+// v_mfma_f32_32x32x16_f16, identical accumulation order => identical results), but organised so
+// that the matrix pipe never waits for a fragment read or a DMA round trip:
+//
+//  * tile 256 x BN (BN = 256: 2x4 waves of 128x64; BN = 128: 4x2 waves of 64x64), one workgroup per
+//    CU, two waves per SIMD.  A K slice costs 48 (24) MFMAs per wave = 3072 (1536) matrix cycles per
+//    SIMD against one DMA of 64 (48) KiB: half (three quarters of) the operand bytes per FLOP of the
+//    128x128 kernel, and a whole iteration for the DMA to land.
+//  * two LDS stages, ONE barrier per slice.  Per iteration kt:
+//        issue reads F1 <- (slice kt, k-half 1)        | MFMAs on F0 (slice kt, k-half 0)
+//        wait lgkmcnt(0), vmcnt(0); s_barrier           -- slice kt+1 visible, slice kt's stage dead
+//        issue reads F0 <- (slice kt+1, k-half 0); DMA slice kt+2 -> dead stage | MFMAs on F1
+//    The fragment reads are inline-asm ds_read_b128: the compiler's waitcnt pass would otherwise
+//    drain the pending LDS-DMA (vmcnt(0)) in front of every LDS read.
+#include "fcp_conv_common.h"
+
+#include <type_traits>
+
+using namespace fcp_conv;
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BMB = 256;          // rows per workgroup tile
+constexpr int NT = 512;           // threads per workgroup
+constexpr int ROWB = 128;         // bytes per LDS row (32 hi + 32 lo binary16)
+constexpr int STAGE = 1 << 16;    // stage stride (power of two: the stage toggles by XOR)
+
+template <int IMM>
+__device__ __forceinline__ f16x8 lds_read128(unsigned addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+  return v;
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// Rows [crow + g*RPP] of a staged 256 x 128 fp32 tile -> fused epilogue, 8 channels per lane.
+__device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, int tile_m, int co_base, int tid, int hw) {
+  constexpr int CPR = 128 / 8, RPP = NT / CPR, PASSES = BMB / RPP;
+  const int ccol = (tid % CPR) * 8;
+  const int crow = tid / CPR;
+  const int co = co_base + ccol;
+  if (co >= p.cout) return;
+  const long m0 = (long)tile_m * BMB + crow;
+  float bias8[8], ws8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bias8[e] = p.bias != nullptr ? p.bias[co + e] : 0.f;
+    ws8[e] = p.wscale[co + e];
+  }
+#pragma unroll 2
+  for (int g = 0; g < PASSES; ++g) {
+    const int row = crow + g * RPP;
+    const long m = m0 + (long)g * RPP;
+    if (m >= p.M) continue;
+    float v[8], r1[8], r2[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * 128 + ccol);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * 128 + ccol + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+    if (p.res1 != nullptr) {
+      long rpix = m;
+      if (p.res1_resize) {
+        const int ni = (int)(m / hw);
+        const int rem = (int)(m - (long)ni * hw);
+        const int ho = rem / p.out_w;
+        const int wo = rem - ho * p.out_w;
+        int sh = (int)floorf(ho * p.res1_sh);
+        int sw = (int)floorf(wo * p.res1_sw);
+        sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
+        sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
+        rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
+      }
+      load8(p.res1, rpix, p.res1_ld, co, p.res1_fmt, r1);
+    }
+    if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, co, p.res2_fmt, r2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = v[e] * ws8[e] + bias8[e];
+      if (p.res1 != nullptr && p.res1_pre) x += r1[e];
+      x = x >= 0.f ? x : x * p.act_slope;
+      x = x * p.alpha;
+      if (p.res1 != nullptr && !p.res1_pre) x += r1[e];
+      if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
+      v[e] = x;
+    }
+    if (p.out_fmt == 1) {
+      u32x4_t hi, lo;
+      split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+      char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + split_chan_off(co);
+      *reinterpret_cast<u32x4_t*>(ob) = hi;
+      *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
+    } else {
+      float* dst = p.out + m * p.out_ld + co;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+}
+
+template <int BN>
+__global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
+  constexpr int WAVES_N = BN == 256 ? 4 : 2;
+  constexpr int WAVES_M = 8 / WAVES_N;
+  constexpr int WTM = BMB / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_LD = BMB / 64, B_LD = BN / 64;   // DMA instructions per thread and slice
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+
+  const int nb = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_n = logical % p.grid_n;
+  const int tile_m = logical / p.grid_n;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_u / WAVES_N, wn = wave_u % WAVES_N;
+  const int lrow = tid >> 3;                                     // 0..63 (+64 i)
+  const int csrc = (tid & 7) ^ (((lrow >> 1) & 7) ^ ((lrow & 1) << 2));
+
+  const int hw = p.out_h * p.out_w;
+  TapPiece tp[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = tile_m * BMB + lrow + 64 * i;
+    unsigned pbase = 0;
+    int hi0 = -(1 << 28), wi0 = 0;
+    if (m < p.M) {
+      const int ni = m / hw;
+      const int rem = m - ni * hw;
+      const int ho = rem / p.out_w;
+      const int wo = rem - ho * p.out_w;
+      pbase = (unsigned)(ni * p.ph * p.pw);
+      hi0 = ho * p.stride - p.pad;
+      wi0 = wo * p.stride - p.pad;
+    }
+    tp[i] = make_tap_piece<false>(p, pbase, hi0, wi0, (unsigned)(csrc * 4));
+  }
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+  unsigned woff[B_LD];
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((tile_n * BN + lrow + 64 * i) * p.wrow + csrc * 4) * 4);
+
+  unsigned rowoff[A_LD];
+  auto set_tap = [&](int tap, int kh_i, int kw_i) {
+    const unsigned tapoff = (unsigned)((kh_i * p.pw + kw_i) * p.in_ld) * 4u;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) rowoff[i] = ((tp[i].mask >> tap) & 1u) ? tp[i].base + tapoff : 0xFFFFFFFFu;
+  };
+  int tap = 0, kh_i = 0, kw_i = 0, c0 = 0;
+  auto advance = [&]() {
+    ++tap;
+    if (++kw_i >= p.kw) {
+      kw_i = 0;
+      if (++kh_i >= p.kh) { kh_i = 0; tap = 0; c0 += BK; }
+    }
+    set_tap(tap, kh_i, kw_i);
+  };
+  // one slice: A_LD + B_LD DMA instructions per wave, each 64 lanes x 16 B = rows 8*wave + 64*i .. +7
+  auto dma_slice = [&](int kt, int stage) {
+    char* a = lds + stage * STAGE + wave_u * 8 * ROWB;
+    char* b = a + BMB * ROWB;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const unsigned ro = rowoff[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 64 * i * ROWB), 16,
+                                               (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 64 * i * ROWB), 16,
+                                               (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addresses (stage 0); the stage toggles by XOR with STAGE
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  const int rsw = (((lane & 31) >> 1) & 7) ^ ((lane & 1) << 2);
+  const int half = lane >> 5;
+  const unsigned arow = lds0 + (unsigned)((wm * WTM + (lane & 31)) * ROWB);
+  const unsigned brow = lds0 + (unsigned)((BMB + wn * WTN + (lane & 31)) * ROWB);
+  unsigned aH[2], aL[2], bH[2], bL[2];   // [k-half]
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const unsigned oh = (unsigned)(((2 * s + half) ^ rsw) << 4), ol = (unsigned)(((4 + 2 * s + half) ^ rsw) << 4);
+    aH[s] = arow + oh; aL[s] = arow + ol;
+    bH[s] = brow + oh; bL[s] = brow + ol;
+  }
+
+  f16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];   // [fragment set]
+  auto read_frags = [&](auto set_c, unsigned stage_xor) {   // set s holds k-half s
+    constexpr int set = decltype(set_c)::value;
+    static_for<0, TM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      fah[set][i] = lds_read128<i * 32 * ROWB>(aH[set] ^ stage_xor);
+      fal[set][i] = lds_read128<i * 32 * ROWB>(aL[set] ^ stage_xor);
+    });
+    static_for<0, TN>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      fbh[set][j] = lds_read128<j * 32 * ROWB>(bH[set] ^ stage_xor);
+      fbl[set][j] = lds_read128<j * 32 * ROWB>(bL[set] ^ stage_xor);
+    });
+  };
+  constexpr std::integral_constant<int, 0> SET0{};
+  constexpr std::integral_constant<int, 1> SET1{};
+  auto mfmas = [&](auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[set][i], fbh[set][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][i], fbl[set][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][i], fbh[set][j], acc[i][j], 0, 0, 0);
+  };
+
+  // prologue: slices 0 and 1 in flight, slice 0 landed, its first k-half in F0
+  set_tap(0, 0, 0);
+  dma_slice(0, 0);
+  if (p.ktiles > 1) {
+    advance();
+    dma_slice(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags(SET0, 0u);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  unsigned sx = 0u;                       // XOR of the stage holding slice kt
+  for (int kt = 0; kt < p.ktiles; ++kt) {
+    // ---- k-half 0 of slice kt on the matrix pipe, k-half 1 on its way to registers
+    read_frags(SET1, sx);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(SET0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's part of slice kt+1 has landed
+    __builtin_amdgcn_s_barrier();                          // slice kt+1 visible; nobody reads slice kt's stage again
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < p.ktiles) read_frags(SET0, sx ^ (unsigned)STAGE);
+    if (kt + 2 < p.ktiles) {
+      advance();
+      dma_slice(kt + 2, kt & 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- k-half 1 of slice kt
+    mfmas(SET1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    sx ^= (unsigned)STAGE;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: 128 output columns at a time through a 256 x 128 fp32 LDS tile
+  float* Cs = smem;
+#pragma unroll 1
+  for (int h = 0; h < BN / 128; ++h) {
+    if ((wn * WTN) / 128 == h) {
+      const int cbase = wn * WTN - h * 128;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const int row = wm * WTM + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+            Cs[row * 128 + cbase + j * 32 + (lane & 31)] = acc[i][j][rr];
+          }
+    }
+    __syncthreads();
+    epilogue_rows(p, Cs, tile_m, tile_n * BN + h * 128, tid, hw);
+    __syncthreads();
+  }
+}
+
+template <int BN>
+int launch(ConvK k, hipStream_t s) {
+  static bool attr_set = false;
+  const size_t lds = 2 * (size_t)STAGE;   // two stages; the epilogue's 256 x 128 fp32 tile aliases them
+  if (!attr_set) {
+    FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16x3_big<BN>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  k.grid_m = fcp_cdiv(k.M, BMB);
+  k.grid_n = fcp_cdiv(k.cout, BN);
+  hipLaunchKernelGGL((conv_igemm_f16x3_big<BN>), dim3(k.grid_m * k.grid_n), dim3(NT), lds, s, k);
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace
+
+namespace fcp_conv {
+
+int launch_f16x3_big(const ConvK& k, int tile_n, hipStream_t s) {
+  return tile_n == 256 ? launch<256>(k, s) : launch<128>(k, s);
+}
+
+}  // namespace fcp_conv

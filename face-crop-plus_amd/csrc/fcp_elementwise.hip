@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) f32nchw_to_nhwc4_kernel(const float* __re
 
 __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float* __restrict__ in,
                                                            float* __restrict__ out, int n, int h,
-                                                           int w, int c4, int oh, int ow) {
+                                                           int w, int c4, int out_ld4, int oh, int ow) {
   const long total = (long)n * oh * ow * c4;
   const long stride = (long)gridDim.x * blockDim.x;
   const f32x4* in4 = reinterpret_cast<const f32x4*>(in);
@@ -100,13 +100,13 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float* __restri
         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
       }
     }
-    out4[i] = m;
+    out4[(i / c4) * out_ld4 + cc] = m;
   }
 }
 
 // split32 tensors: one thread per (pixel, 8-channel chunk)
 __global__ void __launch_bounds__(256) maxpool3x3s2_split_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                 int n, int h, int w, int c, int oh, int ow) {
+                                                                 int n, int h, int w, int c, int out_ld, int oh, int ow) {
   const int c8 = c >> 3;
   const long total = (long)n * oh * ow * c8;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_split_kernel(const float* __
     }
     u32x4_t hi, lo;
     split8(f32x4{m[0], m[1], m[2], m[3]}, f32x4{m[4], m[5], m[6], m[7]}, hi, lo);
-    char* qb = ob + (((long)ni * oh + y) * ow + x) * c * 4 + split_chan_off(ch);
+    char* qb = ob + (((long)ni * oh + y) * ow + x) * out_ld * 4 + split_chan_off(ch);
     *reinterpret_cast<u32x4_t*>(qb) = hi;
     *reinterpret_cast<u32x4_t*>(qb + 64) = lo;
   }
@@ -206,27 +206,28 @@ extern "C" int fcp_f32nchw_to_nhwc4_f32(const float* in, float* out, int n, int 
   return 0;
 }
 
-extern "C" int fcp_maxpool3x3s2_nhwc_f32(const float* in, float* out, int n, int h, int w, int c,
+extern "C" int fcp_maxpool3x3s2_nhwc_f32(const float* in, float* out, int n, int h, int w, int c, int out_ld,
                                          int out_h, int out_w, fcp_stream_t stream) {
   FCP_REQUIRE(in && out, "maxpool: null pointer");
-  FCP_REQUIRE(c % 4 == 0, "maxpool: c must be a multiple of 4");
+  FCP_REQUIRE(c % 4 == 0 && out_ld % 4 == 0 && out_ld >= c && ((uintptr_t)out & 15) == 0,
+              "maxpool: c and out_ld must be multiples of 4, out_ld >= c, out 16-byte aligned");
   FCP_REQUIRE(out_h == (h + 2 - 3) / 2 + 1 && out_w == (w + 2 - 3) / 2 + 1, "maxpool: bad output size");
   const long total = (long)n * out_h * out_w * (c / 4);
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
-                     out, n, h, w, c / 4, out_h, out_w);
+                     out, n, h, w, c / 4, out_ld / 4, out_h, out_w);
   FCP_LAUNCH_OK();
   return 0;
 }
 
-extern "C" int fcp_maxpool3x3s2_split32(const float* in, float* out, int n, int h, int w, int c, int out_h,
-                                        int out_w, fcp_stream_t stream) {
+extern "C" int fcp_maxpool3x3s2_split32(const float* in, float* out, int n, int h, int w, int c, int out_ld,
+                                        int out_h, int out_w, fcp_stream_t stream) {
   FCP_REQUIRE(in && out, "maxpool: null pointer");
-  FCP_REQUIRE(c % 32 == 0 && ((uintptr_t)in & 127) == 0 && ((uintptr_t)out & 127) == 0,
-              "maxpool(split32): c must be a multiple of 32 and buffers 128-byte aligned");
+  FCP_REQUIRE(c % 32 == 0 && out_ld % 32 == 0 && out_ld >= c && ((uintptr_t)in & 127) == 0 && ((uintptr_t)out & 127) == 0,
+              "maxpool(split32): c and out_ld must be multiples of 32 (out_ld >= c) and buffers 128-byte aligned");
   FCP_REQUIRE(out_h == (h + 2 - 3) / 2 + 1 && out_w == (w + 2 - 3) / 2 + 1, "maxpool: bad output size");
   const long total = (long)n * out_h * out_w * (c / 8);
   hipLaunchKernelGGL(maxpool3x3s2_split_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
-                     out, n, h, w, c, out_h, out_w);
+                     out, n, h, w, c, out_ld, out_h, out_w);
   FCP_LAUNCH_OK();
   return 0;
 }

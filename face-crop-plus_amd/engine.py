@@ -193,6 +193,9 @@ def _pick_tile_n(cout: int, m: int) -> int:
     return 64
 
 
+BIG_TILES = os.environ.get("FCP_BIG_TILES", "1") != "0"   # offer the 256-row kernel to the autotuner
+
+
 class Autotune:
     """Optional per-shape choice of the N tile: the first launch of an unseen conv shape times the
     candidate tiles with HIP events (costs a sync, so only during warm-up) and caches the winner."""
@@ -215,6 +218,8 @@ class Autotune:
             e1.synchronize()
             times.append(e0.elapsed_time(e1))
         best = candidates[int(np.argmin(times))]
+        if os.environ.get("FCP_AUTOTUNE_LOG"):
+            print("autotune", key, {str(c): round(t / 3 * 1e3, 1) for c, t in zip(candidates, times)}, "->", best, flush=True)
         cls.cache[key] = best
         return best
 
@@ -236,7 +241,7 @@ class ConvStats:
 def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1.0,
          alpha: float = 1.0, res1: Act | None = None, res1_pre: bool = True,
          res2: Act | None = None, alpha2: float = 1.0, in_up2: bool = False,
-         tile_n: int | None = None, out_fmt: int = 0) -> Act:
+         tile_n: int | None = None, out_fmt: int = 0, tile_m: int | None = None) -> Act:
     """Launch one fused convolution.  ``act_slope``: 1 = identity, 0 = ReLU.  ``out_fmt`` selects the
     format of a freshly allocated output (an explicit ``out`` view carries its own)."""
     assert x.c == pc.cin, f"conv expects {pc.cin} input channels, got {x.c}"
@@ -264,6 +269,7 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     d.cout, d.kh, d.kw, d.stride, d.pad = pc.cout, pc.kh, pc.kw, pc.stride, pc.pad
     d.out_h, d.out_w, d.out_ld = oh, ow, out.ld
     d.tile_n = tile_n or _pick_tile_n(pc.cout, m)
+    d.tile_m = tile_m or 128
     d.cin4 = int(pc.cin4)
     d.act_slope, d.alpha, d.alpha2 = act_slope, alpha, alpha2
     d.res1_pre = int(res1_pre)
@@ -273,13 +279,22 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     if res2 is not None:
         assert (res2.n, res2.h, res2.w, res2.c) == (x.n, oh, ow, pc.cout)
         d.res2_ld = res2.ld
-    if tile_n is None and Autotune.enabled and pc.cout > 64:
-        def _launch(t):
-            d.tile_n = t
-            N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
+    big_ok = (pc.precision == 1 and x.fmt == 1 and not pc.cin4 and not in_up2 and pc.cout % 8 == 0
+              and pc.cout >= 128 and m >= 256 * 64)
+    if tile_n is None and tile_m is None and pc.cout > 64 and (Autotune.enabled or Autotune.cache):
         key = (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, m, int(in_up2), res1 is not None, res2 is not None,
                pc.precision, x.fmt, out.fmt)
-        d.tile_n = Autotune.pick(key, [64, 128], _launch)
+        best = Autotune.cache.get(key)          # a tuned shape keeps its tile after tuning is switched off
+        if best is None and Autotune.enabled:
+            def _launch(t):
+                d.tile_m, d.tile_n = t
+                N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
+            cands = [(128, 64), (128, 128)]
+            if big_ok and BIG_TILES:
+                cands += [(256, 128)] + ([(256, 256)] if pc.cout >= 256 else [])
+            best = Autotune.pick(key, cands, _launch)
+        if best is not None:
+            d.tile_m, d.tile_n = best
     timing = ConvStats.timing
     if timing is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -319,12 +334,15 @@ def f32nchw_to_nhwc4(images: torch.Tensor, sub=(0.0, 0.0, 0.0), div: float = 1.0
     return out
 
 
-def maxpool3x3s2(x: Act) -> Act:
+def maxpool3x3s2(x: Act, out: Act | None = None) -> Act:
+    """``out`` may be a channel slice of a wider buffer (same format as ``x``)."""
     assert x.c0 == 0 and x.c == x.ld
     oh, ow = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1
-    out = Act.empty(x.n, oh, ow, x.c, x.buf.device, x.fmt)
+    if out is None:
+        out = Act.empty(x.n, oh, ow, x.c, x.buf.device, x.fmt)
+    assert (out.n, out.h, out.w, out.c, out.fmt) == (x.n, oh, ow, x.c, x.fmt), "maxpool: bad output view"
     fn = N.lib().fcp_maxpool3x3s2_split32 if x.fmt == 1 else N.lib().fcp_maxpool3x3s2_nhwc_f32
-    N.check(fn(x.ptr(), out.ptr(), x.n, x.h, x.w, x.c, oh, ow, N.stream_ptr()), "fcp_maxpool3x3s2")
+    N.check(fn(x.ptr(), out.ptr(), x.n, x.h, x.w, x.c, out.ld, oh, ow, N.stream_ptr()), "fcp_maxpool3x3s2")
     return out
 
 

@@ -74,6 +74,13 @@ class RetinaFace:
                 if (pre + ".downsample.0.weight") in sd:
                     blk["ds"] = pc(sd[pre + ".downsample.0.weight"], None, bn(sd, pre + ".downsample.1"),
                                    stride, 0, dev)
+                    if stride == 1:
+                        # layer1.0: conv3 and the downsample are both 1x1 / stride 1 at the same resolution, so
+                        # bn3(conv3(o)) + bn_d(down(x)) is ONE 1x1 conv over the channel concat [o | x]
+                        # (K = 64 + 64): the 256-channel identity tensor is never written nor re-read
+                        fold = lambda cw, cb: E.fold_bn(sd[pre + cw].numpy(), {q: v.numpy() for q, v in bn(sd, pre + cb).items()}, None)
+                        (w3, b3), (wd, bd) = fold(".conv3.weight", ".bn3"), fold(".downsample.0.weight", ".downsample.1")
+                        blk["c3ds"] = pc(np.concatenate([w3, wd], 1), b3 + bd, None, 1, 0, dev)
                 blocks.append(blk)
         p["blocks"] = blocks
         for i in (1, 2, 3):
@@ -107,10 +114,16 @@ class RetinaFace:
         # channels, same bytes as fp32) so every consumer conv copies its operand instead of converting it
         f = 1 if self.precision == 1 else 0
         x = E.conv(p["stem"], x4, act_slope=0.0, out_fmt=f)
-        x = E.maxpool3x3s2(x)
+        cat = E.Act.empty(x.n, (x.h + 1) // 2, (x.w + 1) // 2, 2 * x.c, x.buf.device, f)   # [conv2 out | pooled stem]
+        x = E.maxpool3x3s2(x, cat.slice(x.c, x.c))
         feats = []
         for blk in p["blocks"]:
             o = E.conv(blk["c1"], x, act_slope=0.0, out_fmt=f)
+            if "c3ds" in blk:
+                E.conv(blk["c2"], o, cat.slice(0, o.c), act_slope=0.0)
+                x = E.conv(blk["c3ds"], cat, act_slope=0.0, out_fmt=f)
+                del cat
+                continue
             o = E.conv(blk["c2"], o, act_slope=0.0, out_fmt=f)
             idt = x if blk["ds"] is None else E.conv(blk["ds"], x, out_fmt=f)
             x = E.conv(blk["c3"], o, act_slope=0.0, res1=idt, res1_pre=True, out_fmt=f)

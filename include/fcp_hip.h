@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 4
+#define FCP_ABI_VERSION 5
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -83,7 +83,7 @@ typedef struct fcp_conv_desc {
                          (rrdb.py:78-79, _layers.py:338,:343) */
   int32_t cout, kh, kw, stride, pad;
   int32_t out_h, out_w, out_ld;
-  int32_t tile_n;     /* 32, 64 or 128: N tile the filter was packed for */
+  int32_t tile_n;     /* N tile: 32, 64 or 128 (256 with tile_m = 256); filters are padded to 128 rows */
   int32_t cin4;       /* 1: cin4 mode */
   float act_slope, alpha, alpha2;
   int32_t res1_pre, res1_ld, res1_h, res1_w, res2_ld;
@@ -95,6 +95,9 @@ typedef struct fcp_conv_desc {
    * instead of converting; producers convert once in their epilogue.  Views must start on a
    * 32-channel group and in_ld / out_ld / res*_ld must be multiples of 32. */
   int32_t in_fmt, out_fmt, res1_fmt, res2_fmt;
+  int32_t tile_m;     /* 0 / 128: 128-row workgroup tiles; 256: the 256-row, 8-wave kernel (precision 1,
+                         split32 input, no cin4 / in_up2; tile_n 128 or 256) */
+  int32_t reserved;
 } fcp_conv_desc;
 
 int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);
@@ -112,11 +115,12 @@ int fcp_f32nchw_to_nhwc4_f32(const float* in, float* out, int n, int h, int w,
                              const float* sub_host, float div, fcp_stream_t stream);
 
 /* MaxPool2d(kernel 3, stride 2, pad 1) on NHWC fp32 (torchvision ResNet stem,
- * _layers.py:247).  c % 4 == 0. */
-int fcp_maxpool3x3s2_nhwc_f32(const float* in, float* out, int n, int h, int w, int c,
+ * _layers.py:247).  c % 4 == 0.  The input is dense (c elements per pixel); the output may be a
+ * channel slice of a wider buffer (out_ld elements per pixel, out_ld >= c). */
+int fcp_maxpool3x3s2_nhwc_f32(const float* in, float* out, int n, int h, int w, int c, int out_ld,
                               int out_h, int out_w, fcp_stream_t stream);
-/* Same on split32 tensors (c % 32 == 0); the maximum is exact (hi + lo decodes exactly). */
-int fcp_maxpool3x3s2_split32(const float* in, float* out, int n, int h, int w, int c,
+/* Same on split32 tensors (c, out_ld % 32 == 0); the maximum is exact (hi + lo decodes exactly). */
+int fcp_maxpool3x3s2_split32(const float* in, float* out, int n, int h, int w, int c, int out_ld,
                              int out_h, int out_w, fcp_stream_t stream);
 /* Format converters between fp32 NHWC and split32 (npix pixels of c channels, c % 32 == 0). */
 int fcp_f32_to_split32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream);

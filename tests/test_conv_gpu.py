@@ -206,3 +206,43 @@ def test_conv_split32_channel_slices(device, precision):
     full = buf.nchw().cpu()
     assert (full[:, 256:384] - ref).abs().max().item() <= _tol(ref)
     assert (full[:, :256] - feat[:, :256]).abs().max().item() <= 2.0 ** -20 * feat.abs().max().item()   # untouched
+
+
+@pytest.mark.parametrize("k,stride,cin,cout,hw", [(1, 1, 64, 256, (18, 22)), (3, 1, 128, 128, (18, 22)), (3, 2, 64, 384, (19, 21)),
+                                                  (1, 2, 256, 512, (18, 22)), (1, 1, 1024, 256, (9, 7)), (3, 1, 32, 200, (16, 16))])
+def test_conv_256_row_tiles(k, stride, cin, cout, hw, device, precision):
+    """The 8-wave 256-row kernel (tile_m=256, tile_n 128 / 256): same operands and accumulation order as the
+    128-row LDS-DMA kernel => bit-identical outputs; also checked against the fp32 reference.  Covers ragged
+    M (not a multiple of 256), cout that is not a multiple of the N tile, residuals in both formats, one slice."""
+    if precision != "f16x3":
+        pytest.skip("split32 tensors exist only on the fp16x3 path")
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(k * 1000 + cin + cout)
+    n, (h, w) = 3, hw
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, stride, k // 2)
+    res = torch.randn(*ref.shape, generator=g)
+    ref = F.relu(ref + res)
+    pc = E.pack_conv(wt, b, None, stride, k // 2, device)
+    xs = E.f32_to_split32(E.Act(_nhwc(x, device)))
+    rs32 = E.Act(_nhwc(res, device))
+    base = E.conv(pc, xs, act_slope=0.0, res1=rs32, res1_pre=True, tile_n=128, tile_m=128)
+    assert (base.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+    for tile_n in (128, 256):
+        out = E.conv(pc, xs, act_slope=0.0, res1=rs32, res1_pre=True, tile_n=tile_n, tile_m=256)
+        assert out.fmt == 0 and torch.equal(out.buf, base.buf), tile_n
+        if cout % 32 == 0:
+            outs = E.conv(pc, xs, act_slope=0.0, res1=E.f32_to_split32(rs32), res1_pre=True, out_fmt=1, tile_n=tile_n,
+                          tile_m=256)
+            assert outs.fmt == 1 and (outs.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+
+
+def test_conv_256_row_tiles_rejects_unsupported(device, precision):
+    from face_crop_plus_amd import engine as E
+    wt, b = torch.randn(128, 64, 1, 1), torch.zeros(128)
+    pc = E.pack_conv(wt, b, None, 1, 0, device)
+    x = E.Act(torch.randn(1, 8, 8, 64, device=device))
+    with pytest.raises(RuntimeError, match="256-row tiles"):      # fp32-format input (and the fp32 path) are not eligible
+        E.conv(pc, x, tile_m=256, tile_n=128)
