@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_f32p = C.c_void_p
 _lib = None
@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
     """Mirror of ``fcp_conv_desc``."""
     _fields_ = [
         ("in_", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
-        ("res1", C.c_void_p), ("res2", C.c_void_p), ("wscale", C.c_void_p),
+        ("res1", C.c_void_p), ("res2", C.c_void_p), ("wscale", C.c_void_p), ("in2", C.c_void_p),
         ("n", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
         ("cin", C.c_int32), ("in_ld", C.c_int32), ("in_up2", C.c_int32),
         ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
@@ -32,7 +32,8 @@ class ConvDesc(C.Structure):
         ("res1_pre", C.c_int32), ("res1_ld", C.c_int32), ("res1_h", C.c_int32),
         ("res1_w", C.c_int32), ("res2_ld", C.c_int32), ("precision", C.c_int32),
         ("in_fmt", C.c_int32), ("out_fmt", C.c_int32), ("res1_fmt", C.c_int32), ("res2_fmt", C.c_int32),
-        ("tile_m", C.c_int32), ("reserved", C.c_int32),
+        ("tile_m", C.c_int32), ("cin2", C.c_int32), ("in2_ld", C.c_int32), ("in2_h", C.c_int32),
+        ("in2_w", C.c_int32), ("in2_stride", C.c_int32),
     ]
 
 

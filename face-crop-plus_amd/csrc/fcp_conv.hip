@@ -341,6 +341,19 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   if (d->res2) k.vec_ok = k.vec_ok && (d->res2_ld % 4 == 0) && (((uintptr_t)d->res2 & 15) == 0);
   static const int ablate_env = getenv("FCP_CONV_ABLATE") ? atoi(getenv("FCP_CONV_ABLATE")) : 0;
   k.ablate = ablate_env;
+  k.in2 = nullptr; k.in2_bytes = 0; k.csplit = d->cin; k.in2_ld = 0; k.ph2 = 0; k.pw2 = 0; k.stride2 = 1;
+  if (d->in2) {
+    FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && !d->in_up2 && d->kh == 1 && d->kw == 1 && d->pad == 0,
+                "conv: a second source needs a 1x1 / pad 0 conv on the fp16x3 path with split32 inputs");
+    FCP_REQUIRE(d->cin2 > 0 && d->cin2 < d->cin && d->cin2 % 32 == 0 && d->in2_ld % 32 == 0 && d->in2_ld >= d->cin2 &&
+                ((uintptr_t)d->in2 & 127) == 0, "conv: in2 must be a 32-channel-group aligned split32 view, 0 < cin2 < cin");
+    FCP_REQUIRE(d->in2_stride >= 1 && d->in2_h > 0 && d->in2_w > 0 && (long)(d->out_h - 1) * d->in2_stride < d->in2_h &&
+                (long)(d->out_w - 1) * d->in2_stride < d->in2_w, "conv: in2 geometry does not cover the output grid");
+    const unsigned long in2_bytes = (unsigned long)d->n * d->in2_h * d->in2_w * d->in2_ld * 4ul;
+    FCP_REQUIRE(in2_bytes < 0xFFFFFFF0ul, "conv: in2 must be below 4 GiB");
+    k.in2 = d->in2; k.in2_bytes = (unsigned)in2_bytes; k.csplit = d->cin - d->cin2; k.in2_ld = d->in2_ld;
+    k.ph2 = d->in2_h; k.pw2 = d->in2_w; k.stride2 = d->in2_stride;
+  }
   k.grid_m = fcp_cdiv(M, BM);
   k.grid_n = fcp_cdiv(d->cout, d->tile_n);
   hipStream_t s = (hipStream_t)stream;
@@ -356,6 +369,7 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
     k.w_bytes = (unsigned)w_bytes;
     // split32 activations: both operands are pure byte copies -> LDS-DMA kernel
     static const int dma_env = getenv("FCP_CONV_DMA") ? atoi(getenv("FCP_CONV_DMA")) : 2;   // 0 off, 2 / 3 = LDS stages
+    FCP_REQUIRE(!k.in2 || big || dma_env, "conv: a second source needs the LDS-DMA kernels (FCP_CONV_DMA != 0)");
     if (big) {
       k.w_bytes = (unsigned)((unsigned long)fcp_cdiv(d->cout, 128) * 128ul * k.wrow * 4ul);   // filters are padded to 128 rows
       return launch_f16x3_big(k, d->tile_n, s);

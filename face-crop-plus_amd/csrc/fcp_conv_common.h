@@ -30,6 +30,10 @@ struct ConvK {
   const float* wscale;  // per-cout power-of-two filter scale (fp16x3 path) or nullptr
   int in_fmt, out_fmt, res1_fmt, res2_fmt;   // 0 = fp32 NHWC, 1 = split32 (see fcp_hip.h)
   int ablate;  // profiling-only knob (env FCP_CONV_ABLATE), 0 in production
+  // second source of a 1x1 conv (channels >= csplit), LDS-DMA kernels only; in2 == nullptr: off
+  const float* in2;
+  unsigned in2_bytes;
+  int csplit, in2_ld, ph2, pw2, stride2;
 };
 
 

@@ -137,11 +137,13 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
 
   const int hw = p.out_h * p.out_w;
   TapPiece tp[A_LD];
+  unsigned base2[A_LD];   // second source of a 1x1 conv (channels >= csplit), or unused
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
     const int m = tile_m * BMB + lrow + 64 * i;
     unsigned pbase = 0;
     int hi0 = -(1 << 28), wi0 = 0;
+    base2[i] = 0xFFFFFFFFu;
     if (m < p.M) {
       const int ni = m / hw;
       const int rem = m - ni * hw;
@@ -150,9 +152,13 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
       pbase = (unsigned)(ni * p.ph * p.pw);
       hi0 = ho * p.stride - p.pad;
       wi0 = wo * p.stride - p.pad;
+      if (p.in2 != nullptr)
+        base2[i] = (((unsigned)(ni * p.ph2 + ho * p.stride2) * (unsigned)p.pw2 + (unsigned)(wo * p.stride2)) * (unsigned)p.in2_ld +
+                    (unsigned)(csrc * 4)) * 4u;
     }
     tp[i] = make_tap_piece<false>(p, pbase, hi0, wi0, (unsigned)(csrc * 4));
   }
+  __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
   unsigned woff[B_LD];
@@ -178,11 +184,20 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   auto dma_slice = [&](int kt, int stage) {
     char* a = lds + stage * STAGE + wave_u * 8 * ROWB;
     char* b = a + BMB * ROWB;
+    if (c0 >= p.csplit) {                  // wave-uniform: this slice comes from the second source
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      const unsigned ro = rowoff[i];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 64 * i * ROWB), 16,
-                                               (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, 0);
+      for (int i = 0; i < A_LD; ++i) {
+        const unsigned ro = base2[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, (__attribute__((address_space(3))) void*)(a + 64 * i * ROWB), 16,
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)((c0 - p.csplit) * 4)), 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const unsigned ro = rowoff[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 64 * i * ROWB), 16,
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)

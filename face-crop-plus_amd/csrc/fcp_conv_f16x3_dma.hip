@@ -71,6 +71,22 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : 3)) conv_igemm_f16x3_dma
   }
   __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+  // optional second source (1x1 convs): channels >= csplit come from in2 sampled at stride2
+  __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2_bytes, 0x00020000);
+  unsigned base2[A_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int m = tile_m * BM + lrow + 32 * i;
+    base2[i] = 0xFFFFFFFFu;
+    if (p.in2 != nullptr && m < p.M) {
+      const int ni = m / hw;
+      const int rem = m - ni * hw;
+      const int ho = rem / p.out_w;
+      const int wo = rem - ho * p.out_w;
+      base2[i] = (((unsigned)(ni * p.ph2 + ho * p.stride2) * (unsigned)p.pw2 + (unsigned)(wo * p.stride2)) * (unsigned)p.in2_ld +
+                  (unsigned)(csrc * 4)) * 4u;
+    }
+  }
   unsigned woff[B_LD];
 #pragma unroll
   for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((tile_n * BN + lrow + 32 * i) * p.wrow + csrc * 4) * 4);
@@ -108,11 +124,20 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : 3)) conv_igemm_f16x3_dma
   auto dma_slice = [&](int kt, int stage) {
     char* a = lds + stage * STAGE + wave_u * 8 * ROWB;
     char* b = a + BM * ROWB;
+    if (c0 >= p.csplit) {                  // wave-uniform: this slice comes from the second source
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      const unsigned ro = rowoff[i];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * i * ROWB), 16,
-                                               (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, 0);
+      for (int i = 0; i < A_LD; ++i) {
+        const unsigned ro = base2[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, (__attribute__((address_space(3))) void*)(a + 32 * i * ROWB), 16,
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)((c0 - p.csplit) * 4)), 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const unsigned ro = rowoff[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * i * ROWB), 16,
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)

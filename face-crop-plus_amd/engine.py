@@ -241,10 +241,13 @@ class ConvStats:
 def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1.0,
          alpha: float = 1.0, res1: Act | None = None, res1_pre: bool = True,
          res2: Act | None = None, alpha2: float = 1.0, in_up2: bool = False,
-         tile_n: int | None = None, out_fmt: int = 0, tile_m: int | None = None) -> Act:
+         tile_n: int | None = None, out_fmt: int = 0, tile_m: int | None = None,
+         x2: Act | None = None, x2_stride: int = 1) -> Act:
     """Launch one fused convolution.  ``act_slope``: 1 = identity, 0 = ReLU.  ``out_fmt`` selects the
-    format of a freshly allocated output (an explicit ``out`` view carries its own)."""
-    assert x.c == pc.cin, f"conv expects {pc.cin} input channels, got {x.c}"
+    format of a freshly allocated output (an explicit ``out`` view carries its own).  ``x2``: second
+    source of a 1x1 conv — the filter's trailing ``x2.c`` input channels read ``x2`` at
+    ``(ho*x2_stride, wo*x2_stride)`` (both sources split32, fp16x3 path)."""
+    assert x.c + (x2.c if x2 is not None else 0) == pc.cin, f"conv expects {pc.cin} input channels, got {x.c}"
     in_h, in_w = (x.h * 2, x.w * 2) if in_up2 else (x.h, x.w)
     oh = (in_h + 2 * pc.pad - pc.kh) // pc.stride + 1
     ow = (in_w + 2 * pc.pad - pc.kw) // pc.stride + 1
@@ -256,6 +259,9 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     m = x.n * oh * ow
     d = N.ConvDesc()
     d.in_, d.w, d.out = x.ptr(), N.ptr(pc.w), out.ptr()
+    if x2 is not None:
+        assert x2.fmt == 1 and x.fmt == 1 and x2.n == x.n, "two-source convs take split32 tensors"
+        d.in2, d.cin2, d.in2_ld, d.in2_h, d.in2_w, d.in2_stride = x2.ptr(), x2.c, x2.ld, x2.h, x2.w, x2_stride
     d.bias = N.ptr(pc.bias)
     d.wscale = N.ptr(pc.wscale)
     d.precision = pc.precision
@@ -283,7 +289,7 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
               and pc.cout >= 128 and m >= 256 * 64)
     if tile_n is None and tile_m is None and pc.cout > 64 and (Autotune.enabled or Autotune.cache):
         key = (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, m, int(in_up2), res1 is not None, res2 is not None,
-               pc.precision, x.fmt, out.fmt)
+               pc.precision, x.fmt, out.fmt, None if x2 is None else (x2.c, x2_stride))
         best = Autotune.cache.get(key)          # a tuned shape keeps its tile after tuning is switched off
         if best is None and Autotune.enabled:
             def _launch(t):

@@ -74,10 +74,11 @@ class RetinaFace:
                 if (pre + ".downsample.0.weight") in sd:
                     blk["ds"] = pc(sd[pre + ".downsample.0.weight"], None, bn(sd, pre + ".downsample.1"),
                                    stride, 0, dev)
-                    if stride == 1:
-                        # layer1.0: conv3 and the downsample are both 1x1 / stride 1 at the same resolution, so
-                        # bn3(conv3(o)) + bn_d(down(x)) is ONE 1x1 conv over the channel concat [o | x]
-                        # (K = 64 + 64): the 256-channel identity tensor is never written nor re-read
+                    if stride == 1 or E.DEFAULT_PRECISION == 1:
+                        # bn3(conv3(o)) + bn_d(down(x)) is ONE 1x1 conv over the channel concat [o | x(::s, ::s)]:
+                        # the downsampled identity tensor is never written nor re-read.  layer1.0 (stride 1, both
+                        # sources at one resolution) reads a real concat buffer; the stride-2 blocks use the
+                        # two-source form of the LDS-DMA kernels (fp16x3 path).
                         fold = lambda cw, cb: E.fold_bn(sd[pre + cw].numpy(), {q: v.numpy() for q, v in bn(sd, pre + cb).items()}, None)
                         (w3, b3), (wd, bd) = fold(".conv3.weight", ".bn3"), fold(".downsample.0.weight", ".downsample.1")
                         blk["c3ds"] = pc(np.concatenate([w3, wd], 1), b3 + bd, None, 1, 0, dev)
@@ -119,10 +120,16 @@ class RetinaFace:
         feats = []
         for blk in p["blocks"]:
             o = E.conv(blk["c1"], x, act_slope=0.0, out_fmt=f)
-            if "c3ds" in blk:
+            if "c3ds" in blk and blk["c2"].stride == 1:
                 E.conv(blk["c2"], o, cat.slice(0, o.c), act_slope=0.0)
                 x = E.conv(blk["c3ds"], cat, act_slope=0.0, out_fmt=f)
                 del cat
+                continue
+            if "c3ds" in blk:
+                o = E.conv(blk["c2"], o, act_slope=0.0, out_fmt=f)
+                x = E.conv(blk["c3ds"], o, act_slope=0.0, out_fmt=f, x2=x, x2_stride=blk["c2"].stride)
+                if blk["feat"]:
+                    feats.append(x)
                 continue
             o = E.conv(blk["c2"], o, act_slope=0.0, out_fmt=f)
             idt = x if blk["ds"] is None else E.conv(blk["ds"], x, out_fmt=f)

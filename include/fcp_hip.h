@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 5
+#define FCP_ABI_VERSION 6
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -76,6 +76,7 @@ typedef struct fcp_conv_desc {
   const float* res1;  /* or NULL */
   const float* res2;  /* or NULL */
   const float* wscale; /* [cout] power-of-two filter scales (precision 1) or NULL */
+  const float* in2;   /* optional second source of a 1x1 conv (see in2_* below) or NULL */
   int32_t n, in_h, in_w; /* logical input size (after the optional x2 upsample) */
   int32_t cin, in_ld;
   int32_t in_up2;     /* 1: physical input is (in_h/2, in_w/2), read at (h>>1, w>>1)
@@ -97,7 +98,12 @@ typedef struct fcp_conv_desc {
   int32_t in_fmt, out_fmt, res1_fmt, res2_fmt;
   int32_t tile_m;     /* 0 / 128: 128-row workgroup tiles; 256: the 256-row, 8-wave kernel (precision 1,
                          split32 input, no cin4 / in_up2; tile_n 128 or 256) */
-  int32_t reserved;
+  /* Two-source 1x1 conv (K concatenation): the trailing cin2 of the cin input channels come from
+   * in2, a split32 tensor (n, in2_h, in2_w, in2_ld) sampled at (ho*in2_stride, wo*in2_stride); the
+   * leading cin - cin2 channels come from `in` as usual.  This is how a ResNet bottleneck's
+   * bn3(conv3(o)) + bn_d(downsample(x)) runs as one convolution over [o | x(::s, ::s)] without ever
+   * materialising the downsampled identity.  Needs kh = kw = 1, pad 0, precision 1, split32 `in`. */
+  int32_t cin2, in2_ld, in2_h, in2_w, in2_stride;
 } fcp_conv_desc;
 
 int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);

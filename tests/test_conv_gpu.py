@@ -246,3 +246,37 @@ def test_conv_256_row_tiles_rejects_unsupported(device, precision):
     x = E.Act(torch.randn(1, 8, 8, 64, device=device))
     with pytest.raises(RuntimeError, match="256-row tiles"):      # fp32-format input (and the fp32 path) are not eligible
         E.conv(pc, x, tile_m=256, tile_n=128)
+
+
+@pytest.mark.parametrize("c1,c2,cout,stride,hw", [(64, 64, 256, 1, (18, 22)), (128, 256, 512, 2, (20, 24)),
+                                                  (256, 512, 1024, 2, (14, 10)), (32, 96, 72, 3, (19, 22))])
+def test_conv_two_sources(c1, c2, cout, stride, hw, device, precision):
+    """1x1 conv over the K concatenation of two tensors, the second sampled at a stride (bottleneck conv3 +
+    downsample in one launch): every tile shape, vs the sum of two fp32 reference convs."""
+    if precision != "f16x3":
+        pytest.skip("two-source convs exist only on the fp16x3 / split32 path")
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(c1 + c2)
+    n, (h, w) = 3, hw
+    H2, W2 = (h - 1) * stride + 1 + (stride > 1), (w - 1) * stride + 1 + (stride > 1)     # even sizes like ResNet's
+    a = torch.randn(n, c1, h, w, generator=g)
+    b = torch.randn(n, c2, H2, W2, generator=g)
+    wa = torch.randn(cout, c1, 1, 1, generator=g) / (c1 + c2) ** 0.5
+    wb = torch.randn(cout, c2, 1, 1, generator=g) / (c1 + c2) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(a, wa, bias) + F.conv2d(b, wb, None, stride))
+    pc = E.pack_conv(torch.cat([wa, wb], 1), bias, None, 1, 0, device)
+    xa = E.f32_to_split32(E.Act(_nhwc(a, device)))
+    wide = E.f32_to_split32(E.Act(_nhwc(torch.cat([torch.randn(n, 32, H2, W2, generator=g), b], 1), device)))
+    xb = wide.slice(32, c2)                                        # a channel slice as second source
+    outs = []
+    for tm, tn in ((128, 64), (128, 128), (256, 128), (256, 256)):
+        if tm == 256 and cout % 8:
+            continue
+        out = E.conv(pc, xa, act_slope=0.0, x2=xb, x2_stride=stride, tile_m=tm, tile_n=tn)
+        assert (out.nchw().cpu() - ref).abs().max().item() <= _tol(ref), (tm, tn)
+        outs.append(out.buf)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    with pytest.raises(RuntimeError, match="second source"):
+        pc3 = E.pack_conv(torch.randn(cout, c1 + c2, 3, 3), None, None, 1, 1, device)
+        E.conv(pc3, xa, x2=xb, x2_stride=stride)
