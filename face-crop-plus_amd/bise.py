@@ -38,6 +38,7 @@ class BiSeNet:
         self.std = [0.229, 0.224, 0.225]
         self.device = None
         self._p = None
+        self.precision = 0
 
     def load(self, device="cuda:0", weights=None, precision=None):
         device = torch.device(device)
@@ -48,6 +49,7 @@ class BiSeNet:
         sd = load_state_dict("bisenet", weights)
         with torch.cuda.device(device), E.default_precision(precision):
             self._p = self._pack(sd, device)
+        self.precision = E.resolve_precision(precision)
         return self
 
     @staticmethod
@@ -120,23 +122,28 @@ class BiSeNet:
     def forward_logits8(self, x4: E.Act) -> E.Act:
         """Normalised NHWC4 input (n,512,512,4) -> class logits at 1/8 resolution (n,64,64,19)."""
         p = self._p
-        x = E.maxpool3x3s2(E.conv(p["stem"], x4, act_slope=0.0))
+        # fp16x3 path: conv-to-conv activations live in split32 (operands are then LDS-DMA copies); the tensors
+        # read by the small attention kernels (avg-pool / scale-add) stay fp32
+        f = 1 if self.precision == 1 else 0
+        sp = (lambda a: E.f32_to_split32(a)) if f else (lambda a: a)
+        x = E.maxpool3x3s2(E.conv(p["stem"], x4, act_slope=0.0, out_fmt=f))
         feats = {}
         fcat = None
         for blk in p["blocks"]:
-            o = E.conv(blk["c1"], x, act_slope=0.0)
-            idt = x if blk["ds"] is None else E.conv(blk["ds"], x)
+            o = E.conv(blk["c1"], x, act_slope=0.0, out_fmt=f)
+            idt = x if blk["ds"] is None else E.conv(blk["ds"], x, out_fmt=f)
             out = None
             if blk["feat"] and blk["li"] == 2:
                 # feat8 is the first half of FFM's concat buffer (torch.cat([fsp, fcp]), _layers.py:358)
-                fcat = E.Act.empty(o.n, o.h, o.w, 256, o.buf.device)
+                fcat = E.Act.empty(o.n, o.h, o.w, 256, o.buf.device, f)
                 out = fcat.slice(0, 128)
-            x = E.conv(blk["c2"], o, out, act_slope=0.0, res1=idt, res1_pre=True)
+            x = E.conv(blk["c2"], o, out, act_slope=0.0, res1=idt, res1_pre=True, out_fmt=f)
             if blk["feat"]:
                 feats[blk["li"]] = x
         feat8, feat16, feat32 = feats[2], feats[3], feats[4]
         # ContextPath (_layers.py:326-346)
-        avg = self._fc(self._avgpool(feat32), p["conv_avg"], 1)                       # (n,128)
+        feat32_f = E.split32_to_f32(feat32) if f else feat32
+        avg = self._fc(self._avgpool(feat32_f), p["conv_avg"], 1)                     # (n,128)
         f32 = E.conv(p["arm32.conv"], feat32, act_slope=0.0)
         att = self._fc(self._avgpool(f32), p["arm32.att"], 2)
         f32s = self._scale_add(f32, att, add_nc=avg)                                  # feat*atten + avg_up
@@ -149,7 +156,7 @@ class BiSeNet:
         feat = E.conv(p["ffm.convblk"], fcat, act_slope=0.0)
         att = self._fc(self._fc(self._avgpool(feat), p["ffm.conv1"], 1), p["ffm.conv2"], 2)
         feat = self._scale_add(feat, att, add_t=feat)                                 # feat*atten + feat
-        out = E.conv(p["out.conv"], feat, act_slope=0.0)
+        out = E.conv(p["out.conv"], sp(feat), act_slope=0.0)                          # fp32 out: out.cls has 19 filters
         return E.conv(p["out.cls"], out)
 
     def parse(self, faces_u8: torch.Tensor):
