@@ -269,8 +269,14 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   FCP_REQUIRE(d != nullptr, "conv: null descriptor");
   FCP_REQUIRE(d->in && d->w && d->out, "conv: null tensor pointer");
   FCP_REQUIRE(d->n > 0 && d->in_h > 0 && d->in_w > 0 && d->cout > 0, "conv: bad sizes");
-  const bool big = d->tile_m == 256;
-  FCP_REQUIRE(d->tile_m == 0 || d->tile_m == 128 || big, "conv: tile_m must be 0/128/256");
+  const bool big = d->tile_m == 256, halo = d->tile_m == 1;
+  FCP_REQUIRE(d->tile_m == 0 || d->tile_m == 128 || big || halo, "conv: tile_m must be 0/128/256 (or 1: halo-tile 3x3)");
+  if (halo)
+    FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && !d->in_up2 && d->kh == 3 && d->kw == 3 && d->stride == 1 &&
+                d->pad == 1 && d->cout <= 32 && d->cout % 8 == 0 && !d->in2 &&
+                (!d->res1 || (d->res1_h == d->out_h && d->res1_w == d->out_w)),
+                "conv: the halo-tile kernel needs a 3x3 / stride 1 / pad 1 conv with cout <= 32 (cout %% 8 == 0) on the "
+                "fp16x3 path with a split32 input, no second source, no resized residual");
   FCP_REQUIRE(d->tile_n == 32 || d->tile_n == 64 || d->tile_n == 128 || (big && d->tile_n == 256),
               "conv: tile_n must be 32/64/128 (or 256 with tile_m 256)");
   if (big)
@@ -370,6 +376,10 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
     // split32 activations: both operands are pure byte copies -> LDS-DMA kernel
     static const int dma_env = getenv("FCP_CONV_DMA") ? atoi(getenv("FCP_CONV_DMA")) : 2;   // 0 off, 2 / 3 = LDS stages
     FCP_REQUIRE(!k.in2 || big || dma_env, "conv: a second source needs the LDS-DMA kernels (FCP_CONV_DMA != 0)");
+    if (halo) {
+      k.w_bytes = (unsigned)((unsigned long)fcp_cdiv(d->cout, 128) * 128ul * k.wrow * 4ul);
+      return launch_f16x3_halo(k, s);
+    }
     if (big) {
       k.w_bytes = (unsigned)((unsigned long)fcp_cdiv(d->cout, 128) * 128ul * k.wrow * 4ul);   // filters are padded to 128 rows
       return launch_f16x3_big(k, d->tile_n, s);

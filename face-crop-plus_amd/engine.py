@@ -287,7 +287,9 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
         d.res2_ld = res2.ld
     big_ok = (pc.precision == 1 and x.fmt == 1 and not pc.cin4 and not in_up2 and pc.cout % 8 == 0
               and pc.cout >= 128 and m >= 256 * 64)
-    if tile_n is None and tile_m is None and pc.cout > 64 and (Autotune.enabled or Autotune.cache):
+    halo_ok = (pc.precision == 1 and x.fmt == 1 and not pc.cin4 and not in_up2 and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1)
+               and pc.cout <= 32 and pc.cout % 8 == 0 and x2 is None and (res1 is None or (res1.h, res1.w) == (oh, ow)))
+    if tile_n is None and tile_m is None and (pc.cout > 64 or halo_ok) and (Autotune.enabled or Autotune.cache):
         key = (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, m, int(in_up2), res1 is not None, res2 is not None,
                pc.precision, x.fmt, out.fmt, None if x2 is None else (x2.c, x2_stride))
         best = Autotune.cache.get(key)          # a tuned shape keeps its tile after tuning is switched off
@@ -296,6 +298,8 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
                 d.tile_m, d.tile_n = t
                 N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
             cands = [(128, 64), (128, 128)]
+            if halo_ok:
+                cands = [(128, 32), (128, 64), (1, 32)]
             if big_ok and BIG_TILES:
                 cands += [(256, 128)] + ([(256, 256)] if pc.cout >= 256 else [])
             best = Autotune.pick(key, cands, _launch)

@@ -280,3 +280,36 @@ def test_conv_two_sources(c1, c2, cout, stride, hw, device, precision):
     with pytest.raises(RuntimeError, match="second source"):
         pc3 = E.pack_conv(torch.randn(cout, c1 + c2, 3, 3), None, None, 1, 1, device)
         E.conv(pc3, xa, x2=xb, x2_stride=stride)
+
+
+@pytest.mark.parametrize("cin,cout,hw,n", [(64, 32, (16, 64), 2), (96, 32, (19, 45), 1), (160, 24, (8, 32), 3), (32, 32, (5, 7), 2),
+                                           (192, 8, (33, 70), 1)])
+def test_conv_halo_tiles(cin, cout, hw, n, device, precision):
+    """The halo-tile 3x3 kernel (tile_m=1, RRDB's 32-filter convs): bit-identical to the implicit-GEMM kernel;
+    ragged patches (H % 8, W % 32 != 0), image borders, odd slice counts, residual + LeakyReLU epilogue."""
+    if precision != "f16x3":
+        pytest.skip("split32 tensors exist only on the fp16x3 path")
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    h, w = hw
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, h, w, generator=g)
+    ref = F.leaky_relu(F.conv2d(x, wt, b, 1, 1), 0.2) * 0.5 + res
+    pc = E.pack_conv(wt, b, None, 1, 1, device)
+    xs = E.f32_to_split32(E.Act(_nhwc(x, device)))
+    rs = E.Act(_nhwc(res, device))
+    base = E.conv(pc, xs, act_slope=0.2, alpha=0.5, res1=rs, res1_pre=False, tile_m=128, tile_n=32)
+    assert (base.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+    out = E.conv(pc, xs, act_slope=0.2, alpha=0.5, res1=rs, res1_pre=False, tile_m=1, tile_n=32)
+    assert torch.equal(out.buf, base.buf)
+    if cout % 32 == 0:                                             # dense-block style: write a slice of a wider split32 buffer
+        wide = E.Act.empty(n, h, w, 96, device, 1)
+        wide.buf.zero_()
+        E.conv(pc, xs, wide.slice(64, 32), act_slope=0.2, tile_m=1, tile_n=32)
+        ref2 = F.leaky_relu(F.conv2d(x, wt, b, 1, 1), 0.2)
+        got = wide.nchw().cpu()
+        assert (got[:, 64:] - ref2).abs().max().item() <= _tol(ref2) and got[:, :64].abs().max().item() == 0
+    with pytest.raises(RuntimeError, match="halo-tile"):
+        E.conv(E.pack_conv(torch.randn(64, cin, 3, 3), None, None, 1, 1, device), xs, tile_m=1, tile_n=64)
