@@ -38,8 +38,8 @@ RETINA_GFLOP_1024 = 226.64      # algorithmic FLOP / image @10
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="detect", choices=["detect", "full"],
                     help="detect = BASELINE configs[1] (detect+align+crop, the headline metric); "
                          "full = configs[2] (detect + RRDB enhance + align + BiSeNet parse, batch 32 @1024)")

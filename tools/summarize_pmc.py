@@ -9,7 +9,7 @@ on gfx950 FETCH_SIZE counts 128-byte requests as 64 B for wide coalesced reads, 
 import collections, csv, json, sys
 
 src, dst = sys.argv[1], sys.argv[2]
-LAUNCHES = 70
+LAUNCHES = int(sys.argv[3]) if len(sys.argv) > 3 else 66      # conv launches of one detection step
 
 
 def load(path):
@@ -19,7 +19,8 @@ def load(path):
     return [v for v in d.values() if "conv_igemm" in v["name"]][-LAUNCHES:]
 
 
-f, w, s = (load(f"{src}/{k}/b_counter_collection.csv") for k in ("fetch", "write", "sq"))
+import glob
+f, w, s = (load(glob.glob(f"{src}/{k}/**/*counter_collection.csv", recursive=True)[0]) for k in ("fetch", "write", "sq"))
 fetch_kib = sum(v["FETCH_SIZE"] for v in f)
 write_kib = sum(v["WRITE_SIZE"] for v in w)
 stem_expected_kib = 64 * 640 * 640 * 16 / 1024          # NHWC4 fp32 input of the batch-64 640^2 stem
@@ -27,7 +28,7 @@ read_corr = 2.0
 mfma_busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in s)
 gui = sum(v["GRBM_GUI_ACTIVE"] for v in s)               # summed over the 8 XCDs
 out = {
-    "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline (batch 64, 640x640), last step's 70 conv launches",
+    "command": f"bench.py --steps 1 --warmup 1 --no-cpu-baseline (batch 64, 640x640), last step's {LAUNCHES} conv launches",
     "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
     "fetch_calibration": {"stem_reported_kib": f[0]["FETCH_SIZE"], "stem_expected_kib": stem_expected_kib,
                           "ratio": f[0]["FETCH_SIZE"] / stem_expected_kib, "correction_applied": read_corr},

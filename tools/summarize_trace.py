@@ -1,0 +1,22 @@
+"""Reduce a rocprofv3 --kernel-trace CSV of bench.py to (a) the per-launch durations of the last full step
+and (b) nothing else — the --stats CSV is copied as is.
+
+    python tools/summarize_trace.py gpurun_out/prof_f16x3/trace profiles/r01_f16x3_bench_step_trace.csv
+"""
+import csv, glob, re, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+path = glob.glob(f"{src}/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+starts = [i for i, r in enumerate(rows) if "u8_to_nhwc4" in r["Kernel_Name"]]
+a, b = starts[-2], starts[-1]           # the last complete step (the final marker starts the roofline pass / tail)
+seg = rows[a:b]
+with open(dst, "w") as f:
+    f.write("kernel,workgroups,duration_us\n")
+    for r in seg:
+        name = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]).split("(")[0]
+        wg = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1) // max(1, int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1))
+        f.write(f'"{name}",{wg},{(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:.1f}\n')
+wall = (int(rows[b]["Start_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e6
+conv = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg if "conv_igemm" in r["Kernel_Name"]) / 1e6
+print(f"step: {len(seg)} launches, {wall:.3f} ms wall, conv {conv:.3f} ms in {sum('conv_igemm' in r['Kernel_Name'] for r in seg)} launches")
