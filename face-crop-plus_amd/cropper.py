@@ -10,6 +10,7 @@ import os
 from collections import defaultdict
 from functools import partial
 from multiprocessing.pool import ThreadPool
+from threading import Lock
 
 import numpy as np
 import torch
@@ -72,6 +73,10 @@ class Cropper:
         self.weights = weights or {}
         self.precision = precision   # "f16x3" (default) | "f32": arithmetic of the conv engine
         self.num_std_landmarks = 5
+        # host I/O threads of process_dir (decode prefetch + asynchronous encode/write around the GPU workers)
+        self.io_threads = max(2, min(16, (os.cpu_count() or 4) // 2))
+        self._writer = None          # set by process_dir: executor the encoded files are written on
+        self._writes = None
 
         if isinstance(self.output_size, int):
             self.output_size = (self.output_size, self.output_size)
@@ -170,7 +175,11 @@ class Cropper:
             if self.strategy == "all":
                 file_name_counts[file_name] += 1
                 name += f"_{file_name_counts[file_name]}"
-            write_image(os.path.join(output_dir, name + ext), np.asarray(face))
+            path = os.path.join(output_dir, name + ext)
+            if self._writer is not None:        # process_dir: encode + write off the GPU worker's thread
+                self._writes.append(self._writer.submit(write_image, path, np.asarray(face)))
+            else:
+                write_image(path, np.asarray(face))
 
     def save_groups(self, faces, file_names, output_dir, attr_groups, mask_groups):
         """cropper.py:611-746: attr x mask cross product of sub-directories."""
@@ -195,6 +204,11 @@ class Cropper:
     def process_batch(self, file_names, input_dir: str, output_dir: str):
         """cropper.py:748-850."""
         images, file_names = read_images(file_names, input_dir)
+        self._process_images(images, file_names, output_dir)
+
+    @torch.no_grad()
+    def _process_images(self, images, file_names, output_dir: str):
+        """Everything of ``process_batch`` after the files have been decoded."""
         if len(images) == 0:
             return
         paddings, landmarks, indices, images_dev = None, None, None, None
@@ -260,13 +274,38 @@ class Cropper:
         file_batches = shard(file_batches)   # rank r of R takes batches r, r+R, ... (no-op single-process)
         if len(file_batches) == 0:
             return
-        worker = partial(self.process_batch, input_dir=input_dir, output_dir=output_dir)
-        with ThreadPool(self.num_processes) as pool:
-            imap = pool.imap_unordered(worker, file_batches)
-            if desc is not None:
-                try:
-                    import tqdm
-                    imap = tqdm.tqdm(imap, total=len(file_batches), desc=desc)
-                except ImportError:
-                    pass
-            list(imap)
+        # Overlapped host I/O: decode is prefetched `depth` batches ahead on an I/O pool, the
+        # `num_processes` GPU workers of the reference's ThreadPool only run the device pipeline, and the
+        # encoded crops / masks are written asynchronously on the same I/O pool.  File naming, warn-and-skip
+        # and the output directory layout are exactly those of the synchronous `process_batch`.
+        from concurrent.futures import ThreadPoolExecutor
+        depth = max(2, 2 * self.num_processes)
+        io = ThreadPoolExecutor(max_workers=self.io_threads, thread_name_prefix="fcp-io")
+        self._writer, self._writes = io, []
+        reads = {i: io.submit(read_images, file_batches[i], input_dir) for i in range(min(depth, len(file_batches)))}
+        lock = Lock()
+
+        def worker(i):
+            fut = reads.pop(i, None)
+            images, names = fut.result() if fut is not None else read_images(file_batches[i], input_dir)
+            with lock:
+                nxt = i + depth
+                if nxt < len(file_batches) and nxt not in reads:
+                    reads[nxt] = io.submit(read_images, file_batches[nxt], input_dir)
+            self._process_images(images, names, output_dir)
+
+        try:
+            with ThreadPool(self.num_processes) as pool:
+                imap = pool.imap(worker, range(len(file_batches)))
+                if desc is not None:
+                    try:
+                        import tqdm
+                        imap = tqdm.tqdm(imap, total=len(file_batches), desc=desc)
+                    except ImportError:
+                        pass
+                list(imap)
+            for w in self._writes:
+                w.result()                       # surface encode / write errors
+        finally:
+            self._writer, self._writes = None, None
+            io.shutdown(wait=True)

@@ -131,3 +131,33 @@ def test_nonsquare_resize_all_strategy_with_parse(tmp_path, device):
         got = np.asarray(Image.open(out / "hair" / fn).convert("RGB"))
         assert got.shape == (64, 48, 3) and (got != crops[face]).mean() < 0.01
     assert sorted(os.listdir(out / "hair_mask")) == written
+
+
+def test_process_dir_pipeline_is_deterministic(tmp_path, device):
+    """Overlapped decode / device / encode pipeline: the output set does not depend on the number of GPU
+    workers or I/O threads, and equals what the synchronous process_batch writes."""
+    from PIL import Image
+    from face_crop_plus_amd import Cropper
+    src = tmp_path / "many"
+    src.mkdir()
+    rng = np.random.default_rng(5)
+    for i in range(13):
+        h, w = int(rng.integers(90, 200)), int(rng.integers(90, 200))
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(src / f"im{i:02d}.png")
+    (src / "zz_broken.png").write_bytes(b"nope")
+    kw = dict(output_size=64, resize_size=160, strategy="all", det_threshold=0.55, batch_size=3, device="cuda:0",
+              weights={"retinaface": "generated"})
+    outs = []
+    for k, (np_, io) in enumerate(((1, 2), (3, 5))):
+        c = Cropper(num_processes=np_, **kw)
+        c.io_threads = io
+        with pytest.warns(UserWarning, match="Could not read"):
+            c.process_dir(str(src), str(tmp_path / f"o{k}"), desc=None)
+        outs.append({f: (tmp_path / f"o{k}" / f).read_bytes() for f in sorted(os.listdir(tmp_path / f"o{k}"))})
+    c = Cropper(**kw)
+    files = sorted(os.listdir(src))
+    with pytest.warns(UserWarning):
+        for i in range(0, len(files), 3):
+            c.process_batch(files[i:i + 3], str(src), str(tmp_path / "sync"))
+    outs.append({f: (tmp_path / "sync" / f).read_bytes() for f in sorted(os.listdir(tmp_path / "sync"))})
+    assert len(outs[0]) > 5 and outs[0] == outs[1] == outs[2]

@@ -1,0 +1,28 @@
+"""End-to-end process_dir throughput including file decode / encode (not the bench metric) — helper.
+   python tools/bench_process_dir.py [n_files] [size] [num_processes] [io_threads]"""
+import os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from PIL import Image
+from face_crop_plus_amd import Cropper
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 640
+nproc = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+io = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+with tempfile.TemporaryDirectory() as d:
+    src, dst = os.path.join(d, "in"), os.path.join(d, "out")
+    os.makedirs(src)
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 256, (size // 8, size // 8, 3), dtype=np.uint8)
+    img = np.asarray(Image.fromarray(base).resize((size, size), Image.BICUBIC))
+    for i in range(n):
+        Image.fromarray(np.roll(img, i, 1)).save(os.path.join(src, f"{i:05d}.jpg"), quality=90)
+    c = Cropper(resize_size=size, batch_size=64, num_processes=nproc, device="cuda:0", weights={"retinaface": "generated"})
+    if io:
+        c.io_threads = io
+    c.process_dir(src, dst + "_warm", desc=None)
+    t0 = time.time()
+    c.process_dir(src, dst, desc=None)
+    dt = time.time() - t0
+    print(f"{n} jpg {size}x{size}, num_processes={nproc}, io_threads={c.io_threads}, host cores {os.cpu_count()}: "
+          f"{n / dt:.1f} images/s ({len(os.listdir(dst))} crops written)")
