@@ -1,5 +1,5 @@
 // Shader clock under MFMA load: ratio of clock64() (shader cycles) to wall_clock64() (100 MHz).
-// hipcc --offload-arch=gfx950 -O3 tools/probes/clk_probe.hip -o gpurun_out/clk_probe
+// hipcc --offload-arch=gfx950 -O3 tools/probes/clk_probe.hip -o tools/probes/clk_probe.bin; gpurun -- ./tools/probes/clk_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
