@@ -18,8 +18,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("-c", "--config", type=str, help="JSON file whose keys override the defaults below")
     p.add_argument("-i", "--input_dir", type=str, help="directory with input images")
     p.add_argument("-o", "--output-dir", type=str, default=None)
-    p.add_argument("-cn", "--clean-names", action="store_true", help="(not part of the accelerated path: ignored)")
-    p.add_argument("-ci", "--clean-names-inplace", action="store_true", help="(ignored)")
+    p.add_argument("-cn", "--clean-names", action="store_true", help="copy the files to <input_dir>_temp under OS-safe names first (utils.clean_names)")
+    p.add_argument("-ci", "--clean-names-inplace", action="store_true", help="rename the files to OS-safe names in place first")
     p.add_argument("-s", "--output-size", type=int, nargs="+", default=[256, 256])
     p.add_argument("-f", "--output-format", type=str, default=None)
     p.add_argument("-r", "--resize-size", type=int, nargs="+", default=[1024, 1024])
@@ -60,14 +60,24 @@ def parse_args(argv=None) -> dict:
 def main(argv=None):
     kwargs = parse_args(argv)
     input_dir, output_dir = kwargs.pop("input_dir"), kwargs.pop("output_dir")
-    kwargs.pop("clean_names"), kwargs.pop("clean_names_inplace")
+    needs_clean, is_inplace = kwargs.pop("clean_names"), kwargs.pop("clean_names_inplace")
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    temp_dir = None
+    if needs_clean or is_inplace:                       # __main__.py:266-274 of the reference
+        from .utils import clean_names
+        if rank == 0:
+            clean_names(input_dir=input_dir, output_dir=None if is_inplace else input_dir + "_temp")
+        if needs_clean and not is_inplace:
+            output_dir = input_dir + "_faces" if output_dir is None else output_dir
+            input_dir = temp_dir = input_dir + "_temp"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl")
+        dist.barrier()                                  # rank 0 has finished renaming / copying
     from .cropper import Cropper
     cropper = Cropper(**kwargs)
     cropper.process_dir(input_dir, output_dir)
@@ -75,6 +85,9 @@ def main(argv=None):
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if temp_dir is not None and rank == 0:
+        import shutil
+        shutil.rmtree(temp_dir)
 
 
 if __name__ == "__main__":

@@ -86,6 +86,63 @@ def as_batch(images, size=512, padding_mode: str = "constant", device="cuda:0"):
     return batch.cpu().numpy(), unscales, paddings
 
 
+_DEFAULT_EXCLUDE = frozenset("\00!@#$%^&*?={}:;'<>,.?/\\|" + '"')
+
+
+def _to_ascii(name: str) -> str:
+    """Transliterate to ASCII: ``unidecode`` when it is installed (what the reference calls, utils.py:426),
+    otherwise NFKD decomposition with the non-ASCII remainder dropped ("České" -> "Ceske")."""
+    try:
+        import unidecode
+        return unidecode.unidecode(name)
+    except ImportError:
+        import unicodedata
+        return unicodedata.normalize("NFKD", name).encode("ascii", "ignore").decode("ascii")
+
+
+def clean_names(input_dir: str, output_dir: str | None = None, max_chars: int = 250, exclude=_DEFAULT_EXCLUDE,
+                desc: str | None = "Cleaning file names"):
+    """Make the file names of a directory OS-safe (utils.py:344-453): ASCII transliteration of the stem,
+    removal of the ``exclude`` characters from the stem (so one dot remains, the extension's), truncation so
+    that directory + name stays within ``max_chars``, and "-N" suffixes until names are unique
+    case-insensitively.  Files are copied to ``output_dir`` under the new names, or renamed in place when it is
+    None."""
+    import shutil
+    budget = max_chars - len(input_dir)
+    if budget <= 5:
+        raise RuntimeError(f"Directory path length is too long ({len(input_dir)}) Either reduce the length of the "
+                           f"directory name or increase `max_chars`.")
+    if output_dir is not None:
+        os.makedirs(output_dir, exist_ok=True)
+    names = os.listdir(input_dir)
+    if desc is not None:
+        try:
+            import tqdm
+            names = tqdm.tqdm(names, desc=desc)
+        except ImportError:
+            pass
+    seen: dict[str, int] = {}
+    drop = set(exclude)
+    for original in names:
+        stem, ext = os.path.splitext(original)
+        if not stem.isascii():
+            stem = _to_ascii(stem)
+        if drop & set(stem):
+            stem = "".join(ch for ch in stem if ch not in drop)
+        if len(original) > budget:
+            stem = stem[:budget - len(ext)]
+        key = (stem + ext).lower()
+        seen[key] = seen.get(key, -1) + 1
+        while seen[key] > 0:                     # taken: append the running count, then re-check the new name
+            stem += f"-{seen[key]}"
+            key = (stem + ext).lower()
+            seen[key] = seen.get(key, -1) + 1
+        if output_dir is not None:
+            shutil.copy(os.path.join(input_dir, original), os.path.join(output_dir, stem + ext))
+        elif stem + ext != original:
+            os.rename(os.path.join(input_dir, original), os.path.join(input_dir, stem + ext))
+
+
 def write_image(path: str, image: np.ndarray):
     """RGB (or single-channel mask) uint8 array -> file; format from the extension."""
     from PIL import Image

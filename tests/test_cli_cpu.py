@@ -1,5 +1,6 @@
 """CLI flag surface (reference __main__.py:117-226) — host logic only."""
 import json
+import os
 
 import pytest
 
@@ -62,3 +63,28 @@ def test_host_utils(tmp_path):
     lf.write_text("a.png 1 2 3 4 5 6 7 8 9 10\nb.png 2 3 4 5 6 7 8 9 10 11\n")
     lm, fn = utils.parse_landmarks_file(str(lf))
     assert lm.shape == (2, 5, 2) and fn.tolist() == ["a.png", "b.png"]
+
+
+def test_clean_names(tmp_path):
+    """utils.clean_names (reference utils.py:344-453): transliteration, excluded characters, truncation,
+    case-insensitive de-duplication; copy mode and in-place mode."""
+    from face_crop_plus_amd import utils
+    src = tmp_path / "in"
+    src.mkdir()
+    names = ["České.jpg", "a?b#c.d.png", "dup.jpg", "DUP.jpg", "dup-1.jpg", "plain.png", "x" * 80 + ".jpg"]
+    for i, n in enumerate(names):
+        (src / n).write_bytes(bytes([i]))
+    out = tmp_path / "out"
+    utils.clean_names(str(src), str(out), desc=None)
+    got = sorted(os.listdir(out))
+    assert len(got) == len(names) and len({g.lower() for g in got}) == len(names)       # unique ignoring case
+    assert "Ceske.jpg" in got and "abcd.png" in got and "plain.png" in got
+    assert all(g.isascii() and not (set(os.path.splitext(g)[0]) & set("?#.")) for g in got)
+    assert (out / "Ceske.jpg").read_bytes() == bytes([0]) and sorted(os.listdir(src)) == sorted(names)   # copies
+    # truncation budget: max_chars counts the directory path too
+    utils.clean_names(str(src), str(tmp_path / "short"), max_chars=len(str(src)) + 20, desc=None)
+    assert max(len(n) for n in os.listdir(tmp_path / "short")) <= 22                    # 20 + a "-N" suffix at most
+    with pytest.raises(RuntimeError, match="too long"):
+        utils.clean_names(str(src), None, max_chars=len(str(src)) + 3, desc=None)
+    utils.clean_names(str(src), None, desc=None)                                         # in place
+    assert sorted(os.listdir(src)) == got
