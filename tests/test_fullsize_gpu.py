@@ -91,3 +91,37 @@ def test_conv_power_of_two_linearity_full_size(precision, device):
         assert torch.equal(a.buf * 4, b.buf)
     else:
         assert (a.buf * 4 - b.buf).abs().max().item() <= 4e-6 * b.buf.abs().max().item()
+
+
+def test_c5_4k_frames_strategy_all(tmp_path, device):
+    """SURVEY C5 at full geometry: 3840x2160 frames -> GPU batch builder (INTER_AREA to 1024x576 + 224 px pads)
+    -> RetinaFace with strategy "all" (43 008 priors, ~100 faces) -> un-pad -> warp.  Checked end to end against
+    the oracle chain (batch_ref -> retinaface_ref -> align_ref) on the same frames."""
+    from face_crop_plus_amd import Cropper, weights
+    from oracle import retinaface_ref as R, align_ref as A, batch_ref as B
+    rng = np.random.default_rng(21)
+    base = rng.integers(0, 256, (270, 480, 3), dtype=np.uint8)
+    frames = [np.kron(base, np.ones((8, 8, 1), np.uint8)), rng.integers(0, 256, (2160, 3840, 3), dtype=np.uint8)]
+    sd = weights.generate_state_dict("retinaface")
+    c = Cropper(output_size=128, resize_size=1024, strategy="all", det_threshold=0.55, device="cuda:0",
+                weights={"retinaface": sd})
+    from face_crop_plus_amd.batch import build_batch
+    dev_batch, _, pads = build_batch(frames, c.resize_size, "constant", c.device)
+    batch, _, epads = B.as_batch(frames, 1024)
+    assert pads.tolist() == epads.tolist() == [[224, 224, 0, 0]] * 2
+    assert np.array_equal(dev_batch.cpu().numpy(), batch)
+    lm_ref, idx_ref = R.predict(torch.from_numpy(batch).permute(0, 3, 1, 2).float(), sd, "all", 0.55)
+    lm, idx = c.det_model.predict(dev_batch)
+    assert list(idx) == list(idx_ref) and len(idx) > 50                     # same faces per image, same order
+    # Inside the zero padding the input is translation invariant: whole rows of priors tie (or differ by one ulp
+    # of position-dependent summation order), so WHICH of them survives NMS is arithmetic noise on either side.
+    # Faces on image content must agree to the usual tolerance; faces in the bands only in count and row.
+    on_image = (lm_ref[:, :, 1].max(1) >= 224) & (lm_ref[:, :, 1].min(1) < 800)
+    assert on_image.sum() >= 30
+    err = np.abs(lm - lm_ref)
+    assert err[on_image].max() < 2e-3, float(err[on_image].max())
+    assert np.abs(lm[..., 1] - lm_ref[..., 1]).max() < 2e-3                 # band faces: same rows
+    un = lm_ref - epads[idx_ref][:, None, [2, 0]]
+    ref_crops = A.crop_align(batch, epads, idx_ref, un, A.landmarks_target((128, 128), 0.65), (128, 128), "constant")
+    got = c.crop_align(batch, pads, list(idx), lm - pads[idx][:, None, [2, 0]].astype(np.float32))
+    assert got.shape == ref_crops.shape and (got[on_image] != ref_crops[on_image]).mean() < 0.02   # 1e-4 px landmark noise flips some fixed-point roundings
