@@ -48,3 +48,12 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import pytest
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         N.lib()
+
+
+def test_graft_entry_build_in_a_fresh_interpreter():
+    """build() must work when __graft_entry__ is the first thing imported (no stray importlib.util import)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); print('ok')"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
