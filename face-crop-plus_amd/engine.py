@@ -198,8 +198,10 @@ BIG_TILES = os.environ.get("FCP_BIG_TILES", "1") != "0"   # offer the 256-row ke
 
 class Autotune:
     """Optional per-shape choice of the N tile: the first launch of an unseen conv shape times the
-    candidate tiles with HIP events (costs a sync, so only during warm-up) and caches the winner."""
-    enabled = False
+    candidate tiles with HIP events (costs a sync and a handful of extra launches per new shape) and caches the
+    winner; every candidate of the fp16x3 path returns bit-identical tensors, so the choice never changes a
+    result.  On by default (env FCP_AUTOTUNE=0 turns it off); a shape tuned once keeps its tile afterwards."""
+    enabled = os.environ.get("FCP_AUTOTUNE", "1") != "0"
     cache: dict = {}
 
     @classmethod
