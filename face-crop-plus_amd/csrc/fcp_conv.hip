@@ -207,9 +207,9 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
     for (int pp = 0; pp < 4; ++pp) {
       f32x4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + ((p.ablate & 4) ? 0 : i * 32 * LDK + koff[pp]));
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + (FCP_ABLATE(p, 4) ? 0 : i * 32 * LDK + koff[pp]));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + ((p.ablate & 4) ? 0 : j * 32 * LDK + koff[pp]));
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + (FCP_ABLATE(p, 4) ? 0 : j * 32 * LDK + koff[pp]));
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -223,13 +223,13 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
   // park slice kt+1 (other set) in the LDS buffer slice kt-1 just vacated
   auto step = [&](int kt, f32x4 (&ra_ld)[A_LD], f32x4 (&rb_ld)[B_LD], const f32x4 (&ra_st)[A_LD],
                   const f32x4 (&rb_st)[B_LD]) {
-    if (kt + 2 < p.ktiles && !(p.ablate & 1)) {
+    if (kt + 2 < p.ktiles && !FCP_ABLATE(p, 1)) {
       advance();
       load_slice(ra_ld, rb_ld, kt + 2, kh_i, kw_i, c0);
     }
     compute(kt & 1);
-    if (kt + 1 < p.ktiles && !(p.ablate & 2)) store_slice(ra_st, rb_st, (kt + 1) & 1);
-    if (!(p.ablate & 8)) __syncthreads();
+    if (kt + 1 < p.ktiles && !FCP_ABLATE(p, 2)) store_slice(ra_st, rb_st, (kt + 1) & 1);
+    if (!FCP_ABLATE(p, 8)) __syncthreads();
   };
 
   if (BUF) set_tap(0, 0, 0);
@@ -345,8 +345,12 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   k.vec_ok = (d->out_ld % 4 == 0) && (((uintptr_t)d->out & 15) == 0);
   if (d->res1) k.vec_ok = k.vec_ok && (d->res1_ld % 4 == 0) && (((uintptr_t)d->res1 & 15) == 0);
   if (d->res2) k.vec_ok = k.vec_ok && (d->res2_ld % 4 == 0) && (((uintptr_t)d->res2 & 15) == 0);
+#ifdef FCP_CONV_PROFILING
   static const int ablate_env = getenv("FCP_CONV_ABLATE") ? atoi(getenv("FCP_CONV_ABLATE")) : 0;
   k.ablate = ablate_env;
+#else
+  k.ablate = 0;
+#endif
   k.in2 = nullptr; k.in2_bytes = 0; k.csplit = d->cin; k.in2_ld = 0; k.ph2 = 0; k.pw2 = 0; k.stride2 = 1;
   if (d->in2) {
     FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && !d->in_up2 && d->kh == 1 && d->kw == 1 && d->pad == 0,

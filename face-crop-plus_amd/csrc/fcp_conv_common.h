@@ -7,6 +7,14 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Profiling knobs (FCP_CONV_ABLATE bit mask: skip loads / stores / barriers to attribute time) exist only in
+// builds made with FCP_BUILD_PROFILING=1 (-DFCP_CONV_PROFILING); production kernels carry none of them.
+#ifdef FCP_CONV_PROFILING
+#define FCP_ABLATE(p, bits) ((p).ablate & (bits))
+#else
+#define FCP_ABLATE(p, bits) 0
+#endif
+
 namespace fcp_conv {
 
 constexpr int BM = 128;   // output pixels per workgroup tile
@@ -29,7 +37,7 @@ struct ConvK {
   unsigned in_bytes, w_bytes;
   const float* wscale;  // per-cout power-of-two filter scale (fp16x3 path) or nullptr
   int in_fmt, out_fmt, res1_fmt, res2_fmt;   // 0 = fp32 NHWC, 1 = split32 (see fcp_hip.h)
-  int ablate;  // profiling-only knob (env FCP_CONV_ABLATE), 0 in production
+  int ablate;  // FCP_CONV_ABLATE in profiling builds, otherwise 0 and never read
   // second source of a 1x1 conv (channels >= csplit), LDS-DMA kernels only; in2 == nullptr: off
   const float* in2;
   unsigned in2_bytes;
@@ -343,7 +351,7 @@ __device__ __forceinline__ void conv_epilogue8(const ConvK& p, f32x16 (&acc)[TM]
       if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
       v[e] = x;
     }
-    if (p.ablate & 64) continue;   // profiling only: no output stores
+    if (FCP_ABLATE(p, 64)) continue;   // profiling builds only: no output stores
     if (p.out_fmt == 1) {
       u32x4_t hi, lo;
       split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
