@@ -57,6 +57,8 @@ def parse():
                     help="replay the detection step from a captured HIP graph (small, launch-bound batches)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path")
+    ap.add_argument("--no-live-roofline", action="store_true",
+                    help="time the conv launches in one extra step after the timed region instead of inside it")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batch is split over")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
@@ -168,6 +170,12 @@ def main():
     torch.cuda.synchronize()
     E.Autotune.enabled = False
     face_total.zero_()
+    # roofline evidence: HIP events around every conv launch of the timed steps themselves, on the launch stream
+    # (one event pair costs ~2 us of host time; --no-live-roofline measures one extra step after the timed region
+    # instead, as do --graph / --streams, whose launches cannot carry per-launch events)
+    live = rank == 0 and not args.no_live_roofline and graphed is None and streams[0] is None
+    if live:
+        E.ConvStats.timing = []
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -190,14 +198,17 @@ def main():
     # ---- roofline of the dominant kernel (conv engine): per-launch HIP events on the launch stream
     roofline = None
     if rank == 0:
-        E.ConvStats.timing = []
-        graphed_saved, graphed = graphed, None      # per-launch events need the eager launches
-        step(False)
-        graphed = graphed_saved
-        torch.cuda.synchronize()
-        conv_ms = sum(a.elapsed_time(b) for a, b, _ in E.ConvStats.timing)
-        conv_flops = sum(f for _, _, f in E.ConvStats.timing)
-        launches = len(E.ConvStats.timing)
+        nsteps = args.steps
+        if not live:
+            E.ConvStats.timing = []
+            graphed_saved, graphed = graphed, None      # per-launch events need the eager launches
+            step(False)
+            graphed = graphed_saved
+            torch.cuda.synchronize()
+            nsteps = 1
+        conv_ms = sum(a.elapsed_time(b) for a, b, _ in E.ConvStats.timing) / nsteps
+        conv_flops = sum(f for _, _, f in E.ConvStats.timing) / nsteps
+        launches = len(E.ConvStats.timing) // nsteps
         E.ConvStats.timing = None
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
@@ -220,6 +231,8 @@ def main():
                     "executed_frac": round(achieved * (3 if split else 1) / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per conv launch (PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                     "traffic_source": traffic_src,
+                    "measured": ("HIP events around every conv launch of the timed steps" if live
+                                 else "HIP events around every conv launch of one extra step after the timed region"),
                     "launches_per_step": launches, "algorithmic_gflop_per_step": round(conv_flops / 1e9, 2),
                     "avg_launch_ms": round(conv_ms / launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
 
