@@ -57,9 +57,14 @@ def parse():
                     help="replay the detection step from a captured HIP graph (small, launch-bound batches)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path")
+    ap.add_argument("--free-running", action="store_true",
+                    help="with --streams S: do not re-join the streams after every step (S independent workers)")
     ap.add_argument("--no-live-roofline", action="store_true",
                     help="time the conv launches in one extra step after the timed region instead of inside it")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams the batch is split over")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the batch is split over (2: the two half-batches overlap on the device like "
+                         "process_dir's GPU workers, +4..6 %% over 1; the default stays 1 so that per-launch durations "
+                         "- HIP events here, rocprofv3 in profiles/ - are those of kernels that own the device)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
 
@@ -104,6 +109,7 @@ def main():
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [None]
     chunks = list(torch.chunk(images, len(streams)))
+    face_total_s = {st: torch.zeros((), dtype=torch.int64, device=dev) for st in streams if st is not None}
 
     enh = par = None
     if full:
@@ -154,9 +160,14 @@ def main():
         cur = torch.cuda.current_stream()
         outs = []
         for st, imgs in zip(streams, chunks):
-            st.wait_stream(cur)
+            if not args.free_running:
+                st.wait_stream(cur)
             with torch.cuda.stream(st):
                 outs.append(step_chunk(imgs, count))
+                if count and args.free_running:
+                    face_total_s[st].add_(outs[-1][1])
+        if args.free_running:
+            return [c for c, _ in outs]          # the streams stay de-phased, like process_dir's GPU workers
         for st in streams:
             cur.wait_stream(st)
         if count:
@@ -180,6 +191,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    for v in face_total_s.values():
+        v.zero_()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
@@ -187,6 +200,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    for v in face_total_s.values():
+        face_total.add_(v)
     faces = face_total.clone()
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -202,7 +217,8 @@ def main():
         if not live:
             E.ConvStats.timing = []
             graphed_saved, graphed = graphed, None      # per-launch events need the eager launches
-            step(False)
+            for imgs in chunks:                         # sub-batches one after the other on ONE stream: kernels that
+                step_chunk(imgs, False)                 # share the device would inflate each other's durations
             graphed = graphed_saved
             torch.cuda.synchronize()
             nsteps = 1
@@ -232,7 +248,7 @@ def main():
                     "traffic_unit": "HBM bytes per conv launch (PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                     "traffic_source": traffic_src,
                     "measured": ("HIP events around every conv launch of the timed steps" if live
-                                 else "HIP events around every conv launch of one extra step after the timed region"),
+                                 else "HIP events around every conv launch of one extra single-stream pass over the batch after the timed region"),
                     "launches_per_step": launches, "algorithmic_gflop_per_step": round(conv_flops / 1e9, 2),
                     "avg_launch_ms": round(conv_ms / launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
 
@@ -253,7 +269,8 @@ def main():
                                     else "RetinaFace detect + 5-pt align/crop") +
                                    f", batch={args.batch}/GPU synthetic "
                                    f"{args.size}x{args.size} RGB, strategy={args.strategy}, det_threshold=0.6, "
-                                   f"output {args.out_size}x{args.out_size}",
+                                   f"output {args.out_size}x{args.out_size}" +
+                                   (f", {len(streams)} HIP streams x {args.batch // len(streams)} images" if len(streams) > 1 else ""),
                        "global_batch": args.batch * world, "image_size": args.size, "parallelism": f"dp{world}",
                        "faces_per_step": total_faces / max(args.steps, 1),
                        "images_per_s": round(args.batch * world * args.steps / elapsed, 2)},

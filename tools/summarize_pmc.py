@@ -9,7 +9,7 @@ on gfx950 FETCH_SIZE counts 128-byte requests as 64 B for wide coalesced reads, 
 import collections, csv, json, sys
 
 src, dst = sys.argv[1], sys.argv[2]
-LAUNCHES = int(sys.argv[3]) if len(sys.argv) > 3 else 66      # conv launches of one detection step
+LAUNCHES = int(sys.argv[3]) if len(sys.argv) > 3 else 66     # conv launches of one detection step
 
 
 def load(path):

@@ -6,10 +6,12 @@ and (b) nothing else — the --stats CSV is copied as is.
 import csv, glob, re, sys
 
 src, dst = sys.argv[1], sys.argv[2]
+per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # u8_to_nhwc4 launches per step (= --streams)
 path = glob.glob(f"{src}/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "u8_to_nhwc4" in r["Kernel_Name"]]
-a, b = starts[-2], starts[-1]           # the last complete step (the final marker starts the roofline pass / tail)
+# take the last complete timed step (the markers after it belong to the next step / an optional roofline pass)
+a, b = starts[-2 * per_step], starts[-per_step]
 seg = rows[a:b]
 with open(dst, "w") as f:
     f.write("kernel,workgroups,duration_us\n")
