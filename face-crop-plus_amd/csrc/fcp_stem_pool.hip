@@ -1,0 +1,266 @@
+// RetinaFace stem in one pass: uint8 image -> (x - mean) -> 7x7 / stride 2 / pad 3 conv (3 -> 64, BatchNorm
+// folded) -> ReLU -> 3x3 / stride 2 / pad 1 max-pool, written as a (split32 or fp32) NHWC channel slice.
+// Replaces u8_to_nhwc4 + conv + max-pool (reference retinaface.py:450-451 and the torchvision ResNet stem,
+// _layers.py / retinaface.py:93-99): the 320x320x64 stem map (1.7 GB for a batch of 64 at 640^2) never
+// reaches HBM; only the uint8 image is read and the pooled map written.
+//
+// Arithmetic.  x - mean is an integer in [-123, 151], exact in binary16, so the activation operand has no
+// lo part and the fp16x3 product needs two matrix instructions, a*wh + a*wl (weights pre-scaled per filter by
+// a power of two and split hi + lo offline, like every other filter of the fp16x3 path), accumulated in
+// fp32 — the same accuracy class as the generic kernels, with a different (kh, kw*3+c) summation order.
+//
+// Mapping.  A persistent workgroup (4 waves, one per SIMD) walks patches of 6 x 16 pooled pixels.  A patch
+// needs 13 x 33 stem pixels (14 MFMA row tiles of 32) from a 31 x 71 pixel image patch, which is staged in LDS
+// as raw bytes (out-of-image bytes = the channel mean, i.e. the conv's zero padding).  K = 7 filter rows x 24
+// (21 = 7 taps x 3 channels, padded): a lane's 8 consecutive K values are 8 consecutive bytes of one image
+// row, converted to binary16 with two byte-permutes (0x6400 | b = 1024 + b) and one packed subtract.  All 44
+// filter fragments (2 column tiles x 11 k-steps x hi/lo) live in registers for the lifetime of the workgroup.
+// The stem tile goes to LDS as fp32 (bias, ReLU, -inf outside the stem map = the pool's padding), is
+// max-pooled there and leaves as 16-byte stores.
+#include "fcp_conv_common.h"
+
+using namespace fcp_conv;
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PH = 4, PW = 16;                 // pooled pixels per patch
+constexpr int SH = 2 * PH + 1, SW = 2 * PW + 1;  // stem pixels per patch: 9 x 33
+constexpr int NSTEM = SH * SW;                 // 297
+constexpr int NTILES = (NSTEM + 31) / 32;      // 10
+constexpr int IH = 2 * SH + 5;                 // 23 image rows (+1 spare row for the padded K chunk)
+constexpr int IWB = (2 * SW + 5) * 3;          // 213 bytes per image row of the patch
+constexpr int IPITCH = 216;                    // binary16 elements per staged image row
+constexpr int IN_ELEMS = (IH + 1) * IPITCH;    // 5184 halves = 10 368 B
+constexpr int NT = 512;                         // 8 waves: (row-tile group 0..3) x (column tile 0..1)
+constexpr int NLOAD = (IH * IWB + NT - 1) / NT;  // 10 bytes per thread
+constexpr int SPITCH = 68;                     // floats per staged stem pixel (64 + 4: conflict-free pooling)
+constexpr int KSTEPS = 11;                     // 22 chunks of 8 K values (7 rows x 3 chunks, +1 zero chunk)
+
+struct StemParams {
+  const uint8_t* img;
+  const uint32_t* wfrag;   // [2 column tiles][11 k-steps][hi, lo][64 lanes][4 dwords]
+  const float* bias;
+  const float* wscale;
+  float* out;
+  int n, h, w, hs, ws, hp, wp, out_ld, out_fmt;
+  int tiles_y, tiles_x, npatches;
+  int mean[3];
+};
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain vmcnt, i.e. park every wave
+// until the pooled pixels of this patch have reached HBM and the next patch's bytes have arrived.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ __attribute__((aligned(16))) _Float16 inh[IN_ELEMS];   // (x - mean) as binary16: exact integers
+  float* stage = smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+
+  // this wave's column tile (32 filters) and row-tile group; its 22 filter fragments (11 k-steps x hi / lo) stay in
+  // registers for the whole kernel
+  const int ct = wave & 1, grp = wave >> 1;
+  f16x8 wh[KSTEPS], wl[KSTEPS];
+#pragma unroll
+  for (int q = 0; q < KSTEPS; ++q) {
+    const u32x4_t* src = reinterpret_cast<const u32x4_t*>(p.wfrag) + ((ct * KSTEPS + q) * 2) * 64 + lane;
+    wh[q] = __builtin_bit_cast(f16x8, src[0]);
+    wl[q] = __builtin_bit_cast(f16x8, src[64]);
+  }
+
+  // pooling pass: a thread always handles the same 8 channels (item & 7 == tid & 7)
+  float bias8[8], ws8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bias8[e] = p.bias[(tid & 7) * 8 + e];
+    ws8[e] = p.wscale[(tid & 7) * 8 + e];
+  }
+
+  // this thread's share of the image patch: byte index b -> (row, byte column)
+  int lrow[NLOAD], lcol[NLOAD];
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    const int b = tid + NT * i;
+    lrow[i] = b / IWB;
+    lcol[i] = b - lrow[i] * IWB;
+  }
+  // Per byte of this thread's share: LDS element offset, pixel column inside the patch, channel mean.
+  int lxc[NLOAD], lmean[NLOAD], loff[NLOAD];
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    lxc[i] = lcol[i] / 3;
+    lmean[i] = p.mean[lcol[i] - lxc[i] * 3];
+    loff[i] = lrow[i] < IH ? lrow[i] * IPITCH + lcol[i] : -1;
+  }
+  // fetch(): branch-free byte loads from clamped (always valid) addresses, nothing consumed before commit(), so
+  // all of them are in flight under the MFMAs of the current patch
+  uint8_t pre[NLOAD];
+  unsigned pre_ok = 0u;
+  auto fetch = [&](int patch) {
+    const int pxi = patch % p.tiles_x;
+    const int pyi = (patch / p.tiles_x) % p.tiles_y;
+    const int ni = patch / (p.tiles_x * p.tiles_y);
+    const int iy0 = 4 * pyi * PH - 5, ix0 = 4 * pxi * PW - 5;
+    const uint8_t* base = p.img + (long)ni * p.h * p.w * 3;
+    pre_ok = 0u;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int y = iy0 + lrow[i], x = ix0 + lxc[i];
+      const bool ok = (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
+      pre_ok |= ok ? (1u << i) : 0u;
+      const int yc = min(max(y, 0), p.h - 1), xc = min(max(x, 0), p.w - 1);
+      pre[i] = base[((long)yc * p.w + xc) * 3 + (lcol[i] - lxc[i] * 3)];
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i)
+      if (loff[i] >= 0)     // x - mean, or 0 outside the image (the conv's zero padding)
+        inh[loff[i]] = (_Float16)(float)(((pre_ok >> i) & 1u) ? (int)pre[i] - lmean[i] : 0);
+  };
+
+  // zero the spare row / pitch padding once (read by the zero-weight K chunk: must be finite)
+  for (int i = tid; i < IN_ELEMS / 2; i += NT) reinterpret_cast<uint32_t*>(inh)[i] = 0u;
+  __syncthreads();
+
+  // image-patch byte offset of this lane's stem pixel in each of the wave's row tiles (patch independent)
+  int abase_t[(NTILES + 3) / 4];
+#pragma unroll
+  for (int k = 0; k < (NTILES + 3) / 4; ++k) {
+    int pix = (grp + 4 * k) * 32 + (lane & 31);
+    pix = pix < NSTEM ? pix : NSTEM - 1;
+    const int si = pix / SW, sj = pix - si * SW;
+    abase_t[k] = (2 * si) * IPITCH + 6 * sj;
+  }
+
+  int patch = blockIdx.x;
+  if (patch < p.npatches) fetch(patch);
+  for (; patch < p.npatches; patch += gridDim.x) {
+    commit();
+    lds_barrier();                                      // image patch visible
+    const int next = patch + gridDim.x;
+    if (next < p.npatches) fetch(next);                 // global loads of the next patch fly under the MFMAs
+
+    const int pxi = patch % p.tiles_x;
+    const int pyi = (patch / p.tiles_x) % p.tiles_y;
+    const int ni = patch / (p.tiles_x * p.tiles_y);
+    const int py0 = pyi * PH, px0 = pxi * PW;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
+
+#pragma unroll
+    for (int k = 0; k < (NTILES + 3) / 4; ++k) {
+      const int t = grp + 4 * k;
+      if (t >= NTILES) break;
+      const int abase = abase_t[k];
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int q = 0; q < KSTEPS; ++q) {
+        const int ch = 2 * q + half;                     // K chunk of this lane: filter row ch / 3, part ch % 3
+        const int kh = ch / 3, part = ch - kh * 3;
+        // 8 consecutive K values = 8 consecutive binary16 of one staged image row (4-byte aligned)
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>(inh + abase + kh * IPITCH + 8 * part);
+        const u32x4_t raw = {wp[0], wp[1], wp[2], wp[3]};
+        const f16x8 a = __builtin_bit_cast(f16x8, raw);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, wl[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, wh[q], acc, 0, 0, 0);
+      }
+      // raw accumulators -> stage.  Scale (> 0), bias and ReLU are monotone per channel, so they commute with the
+      // max and are applied to the pooled pixels instead of the stem pixels
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        if (row < NSTEM) stage[row * SPITCH + ct * 32 + (lane & 31)] = acc[rr];
+      }
+    }
+    lds_barrier();                                      // stem tile staged; image patch no longer read
+
+    // max-pool 3x3 / 2 from LDS, 8 channels per item
+    for (int item = tid; item < PH * PW * 8; item += NT) {
+      const int c8 = (item & 7) * 8, pp = item >> 3;
+      const int py = pp / PW, px = pp - py * PW;
+      const int oy = py0 + py, ox = px0 + px;
+      if (oy >= p.hp || ox >= p.wp) continue;
+      float m[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          // stem pixels outside the stem map are the pool's (-inf) padding
+          if ((unsigned)(sy0 + 2 * py + dy) >= (unsigned)p.hs || (unsigned)(sx0 + 2 * px + dx) >= (unsigned)p.ws) continue;
+          const float* s = stage + ((2 * py + dy) * SW + 2 * px + dx) * SPITCH + c8;
+          const f32x4 u = *reinterpret_cast<const f32x4*>(s), v = *reinterpret_cast<const f32x4*>(s + 4);
+          m[0] = fmaxf(m[0], u[0]); m[1] = fmaxf(m[1], u[1]); m[2] = fmaxf(m[2], u[2]); m[3] = fmaxf(m[3], u[3]);
+          m[4] = fmaxf(m[4], v[0]); m[5] = fmaxf(m[5], v[1]); m[6] = fmaxf(m[6], v[2]); m[7] = fmaxf(m[7], v[3]);
+        }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = m[e] * ws8[e] + bias8[e];
+        m[e] = v > 0.f ? v : 0.f;
+      }
+      const long pixel = ((long)ni * p.hp + oy) * p.wp + ox;
+      if (p.out_fmt == 1) {
+        u32x4_t hi, lo;
+        split8(f32x4{m[0], m[1], m[2], m[3]}, f32x4{m[4], m[5], m[6], m[7]}, hi, lo);
+        char* ob = reinterpret_cast<char*>(p.out) + pixel * p.out_ld * 4 + split_chan_off(c8);
+        *reinterpret_cast<u32x4_t*>(ob) = hi;
+        *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
+      } else {
+        float* dst = p.out + pixel * p.out_ld + c8;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{m[0], m[1], m[2], m[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{m[4], m[5], m[6], m[7]};
+      }
+    }
+    lds_barrier();                                      // stage free for the next patch
+  }
+}
+
+}  // namespace
+
+extern "C" int fcp_stem7x7s2_relu_pool_u8(const uint8_t* images, int n, int h, int w, const int32_t* mean_rgb,
+                                          const void* wfrag, const float* bias, const float* wscale, float* out,
+                                          int out_ld, int out_fmt, fcp_stream_t stream) {
+  FCP_REQUIRE(images && wfrag && bias && wscale && out && mean_rgb, "stem: null pointer");
+  FCP_REQUIRE(n > 0 && h >= 1 && w >= 1, "stem: bad image size");
+  FCP_REQUIRE((unsigned)out_fmt <= 1u, "stem: out_fmt must be 0 (fp32) or 1 (split32)");
+  FCP_REQUIRE(out_ld >= 64 && out_ld % (out_fmt ? 32 : 4) == 0 && ((uintptr_t)out & (out_fmt ? 127 : 15)) == 0,
+              "stem: misaligned output view");
+  FCP_REQUIRE(((uintptr_t)wfrag & 15) == 0, "stem: filter fragments must be 16-byte aligned");
+  for (int c = 0; c < 3; ++c) FCP_REQUIRE(mean_rgb[c] >= 0 && mean_rgb[c] <= 255, "stem: means must be integers in 0..255");
+  StemParams p;
+  p.img = images; p.wfrag = static_cast<const uint32_t*>(wfrag); p.bias = bias; p.wscale = wscale; p.out = out;
+  p.n = n; p.h = h; p.w = w;
+  p.hs = (h + 6 - 7) / 2 + 1; p.ws = (w + 6 - 7) / 2 + 1;
+  p.hp = (p.hs + 2 - 3) / 2 + 1; p.wp = (p.ws + 2 - 3) / 2 + 1;
+  p.out_ld = out_ld; p.out_fmt = out_fmt;
+  p.tiles_y = fcp_cdiv(p.hp, PH); p.tiles_x = fcp_cdiv(p.wp, PW);
+  const long np = (long)n * p.tiles_y * p.tiles_x;
+  FCP_REQUIRE(np < (1L << 31) && (long)n * h * w * 3 < (1L << 40), "stem: batch too large");
+  p.npatches = (int)np;
+  for (int c = 0; c < 3; ++c) p.mean[c] = mean_rgb[c];
+  static bool attr_set = false;
+  const size_t lds = (size_t)NSTEM * SPITCH * 4;       // stem staging (the binary16 image patch is a static array)
+  if (!attr_set) {
+    FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int grid = (int)(np < 256 ? np : 256);
+  hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, p);
+  FCP_LAUNCH_OK();
+  return 0;
+}

@@ -334,6 +334,75 @@ def u8_to_nhwc4(images_u8: torch.Tensor, sub=(0.0, 0.0, 0.0), div: float = 1.0) 
     return out
 
 
+@dataclass
+class PackedStem:
+    wfrag: torch.Tensor      # int16 [2][11][2][64][8]: binary16 hi / lo filter fragments (MFMA operand order)
+    bias: torch.Tensor
+    wscale: torch.Tensor
+    flops_per_pixel: int     # algorithmic FLOP per stem output pixel (2 * 64 * 3 * 49)
+
+
+def pack_stem_fused(weight, bn, device, cin_perm=None) -> PackedStem:
+    """Filter of the fused uint8 -> 7x7/2 conv -> ReLU -> max-pool kernel (fcp_stem7x7s2_relu_pool_u8).
+    weight (64,3,7,7); K index = kh*24 + kw*3 + c, 22 chunks of 8 (the last one, and k % 24 >= 21, zero)."""
+    if isinstance(weight, torch.Tensor):
+        weight = weight.detach().cpu().numpy()
+    bn = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in bn.items()}
+    w, b = fold_bn(weight, bn, None)
+    if cin_perm is not None:
+        w = w[:, cin_perm]
+    assert w.shape == (64, 3, 7, 7), "the fused stem is the ResNet 7x7 / 64-filter stem"
+    wk = np.zeros((64, 22 * 8), np.float32)
+    wk.reshape(64, 22, 8)                                        # (filter, chunk, element) view of the same K axis
+    for kh in range(7):
+        wk[:, kh * 24:kh * 24 + 21] = w[:, :, kh, :].transpose(0, 2, 1).reshape(64, 21)     # (kw, c) fastest
+    amax = np.abs(wk).max(1)
+    e = np.where(amax > 0, np.floor(np.log2(np.maximum(amax, 1e-38))), 0.0)
+    scale = np.exp2(e).astype(np.float32)
+    ws = wk / scale[:, None]
+    hi = ws.astype(np.float16)
+    lo = (ws - hi.astype(np.float32)).astype(np.float16)
+    frag = np.zeros((2, 11, 2, 64, 8), np.float16)
+    lane = np.arange(64)
+    for ct in range(2):
+        n = ct * 32 + (lane & 31)
+        for q in range(11):
+            ch = 2 * q + (lane >> 5)
+            k = ch[:, None] * 8 + np.arange(8)[None, :]
+            frag[ct, q, 0] = hi[n[:, None], k]
+            frag[ct, q, 1] = lo[n[:, None], k]
+    return PackedStem(torch.from_numpy(np.ascontiguousarray(frag.view(np.int16))).to(device),
+                      torch.from_numpy(np.ascontiguousarray(b)).to(device), torch.from_numpy(scale).to(device),
+                      2 * 64 * 3 * 49)
+
+
+def stem_relu_pool_u8(ps: PackedStem, images_u8: torch.Tensor, out: Act | None = None, mean_rgb=(123, 117, 104),
+                      out_fmt: int = 1) -> Act:
+    """(n,h,w,3) uint8 -> stem conv + ReLU + max-pool, one launch; ``out`` may be a 64-channel slice."""
+    assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[3] == 3 and images_u8.is_contiguous()
+    n, h, w, _ = images_u8.shape
+    hs, ws = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    hp, wp = (hs - 1) // 2 + 1, (ws - 1) // 2 + 1
+    if out is None:
+        out = Act.empty(n, hp, wp, 64, images_u8.device, out_fmt)
+    assert (out.n, out.h, out.w, out.c) == (n, hp, wp, 64), "stem: bad output view"
+    mean = (C.c_int32 * 3)(*[int(m) for m in mean_rgb])
+    timing = ConvStats.timing
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    N.check(N.lib().fcp_stem7x7s2_relu_pool_u8(N.ptr(images_u8), n, h, w, mean, N.ptr(ps.wfrag), N.ptr(ps.bias),
+                                               N.ptr(ps.wscale), out.ptr(), out.ld, out.fmt, N.stream_ptr()),
+            "fcp_stem7x7s2_relu_pool_u8")
+    if timing is not None:
+        e1.record()
+        timing.append((e0, e1, ps.flops_per_pixel * n * hs * ws))
+    if ConvStats.enabled:
+        ConvStats.flops += ps.flops_per_pixel * n * hs * ws
+        ConvStats.launches += 1
+    return out
+
+
 def f32nchw_to_nhwc4(images: torch.Tensor, sub=(0.0, 0.0, 0.0), div: float = 1.0) -> Act:
     """(n,3,h,w) fp32 device tensor -> fp32 NHWC4 activation ((x - sub) / div)."""
     assert images.dtype == torch.float32 and images.dim() == 4 and images.shape[1] == 3

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -35,6 +37,7 @@ class RetinaFace:
         self.device = None
         self._p = None
         self.precision = 0
+        self.fused_stem = os.environ.get("FCP_FUSED_STEM", "1") != "0"   # fp16x3 path: uint8 -> stem + pool in one launch
 
     # ------------------------------------------------------------------ load
     def load(self, device: str | torch.device = "cuda:0", weights=None, precision=None):
@@ -60,6 +63,9 @@ class RetinaFace:
         pc, bn = E.pack_conv, E.bn_of
         # stem: kernel keeps RGB channel order, so swap the filter's input channels (BGR) instead
         p["stem"] = pc(sd["body.conv1.weight"], None, bn(sd, "body.bn1"), 2, 3, dev, cin_perm=[2, 1, 0])
+        if E.DEFAULT_PRECISION == 1:
+            # uint8 batch -> conv1 + bn1 + relu + maxpool in one launch (x - mean is exact in binary16)
+            p["stem_fused"] = E.pack_stem_fused(sd["body.conv1.weight"], bn(sd, "body.bn1"), dev, cin_perm=[2, 1, 0])
         blocks = []
         for li, nb in enumerate((3, 4, 6, 3), 1):
             for b in range(nb):
@@ -108,15 +114,22 @@ class RetinaFace:
         return p
 
     # --------------------------------------------------------------- forward
-    def forward_heads(self, x4: E.Act):
-        """NHWC4 (RGB - mean) -> three fused head maps (n, h/8|16|32, w/.., 32)."""
+    def forward_heads(self, x4: E.Act | None, images_u8: torch.Tensor | None = None):
+        """NHWC4 (RGB - mean) — or, on the fp16x3 path, the uint8 batch itself — -> three fused head maps
+        (n, h/8|16|32, w/.., 32)."""
         p = self._p
         # fp16x3 path: activations between convs live in the "split32" format (hi/lo binary16 planes per 32
         # channels, same bytes as fp32) so every consumer conv copies its operand instead of converting it
         f = 1 if self.precision == 1 else 0
-        x = E.conv(p["stem"], x4, act_slope=0.0, out_fmt=f)
-        cat = E.Act.empty(x.n, (x.h + 1) // 2, (x.w + 1) // 2, 2 * x.c, x.buf.device, f)   # [conv2 out | pooled stem]
-        x = E.maxpool3x3s2(x, cat.slice(x.c, x.c))
+        if images_u8 is not None and "stem_fused" in p:
+            n, h, w, _ = images_u8.shape
+            hp, wp = ((h - 1) // 2) // 2 + 1, ((w - 1) // 2) // 2 + 1
+            cat = E.Act.empty(n, hp, wp, 128, images_u8.device, f)                   # [conv2 out | pooled stem]
+            x = E.stem_relu_pool_u8(p["stem_fused"], images_u8, cat.slice(64, 64))
+        else:
+            x = E.conv(p["stem"], x4, act_slope=0.0, out_fmt=f)
+            cat = E.Act.empty(x.n, (x.h + 1) // 2, (x.w + 1) // 2, 2 * x.c, x.buf.device, f)
+            x = E.maxpool3x3s2(x, cat.slice(x.c, x.c))
         feats = []
         for blk in p["blocks"]:
             o = E.conv(blk["c1"], x, act_slope=0.0, out_fmt=f)
@@ -162,12 +175,18 @@ class RetinaFace:
         """
         if self.strategy not in STRATEGIES:
             raise ValueError(f"Unsupported startegy: {self.strategy}")
-        if x4 is None:
+        fused = x4 is None and "stem_fused" in self._p and self.fused_stem
+        if x4 is None and not fused:
             # RGB order is kept; means are (R,G,B) = (123,117,104) (retinaface.py:450)
             x4 = E.u8_to_nhwc4(images_u8, sub=(123.0, 117.0, 104.0))
-        n, h, w = x4.n, x4.h, x4.w
-        dev = x4.buf.device
-        heads = self.forward_heads(x4)
+        if fused:
+            images_u8 = images_u8.contiguous()
+            (n, h, w), dev = images_u8.shape[:3], images_u8.device
+            heads = self.forward_heads(None, images_u8)
+        else:
+            n, h, w = x4.n, x4.h, x4.w
+            dev = x4.buf.device
+            heads = self.forward_heads(x4)
         P = sum(2 * (-(-h // s)) * (-(-w // s)) for s in (8, 16, 32))
         f32, i32 = torch.float32, torch.int32
         cand_score = torch.empty((n, P), dtype=f32, device=dev)

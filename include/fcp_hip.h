@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 6
+#define FCP_ABI_VERSION 7
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -130,6 +130,17 @@ int fcp_maxpool3x3s2_nhwc_f32(const float* in, float* out, int n, int h, int w, 
 /* Same on split32 tensors (c, out_ld % 32 == 0); the maximum is exact (hi + lo decodes exactly). */
 int fcp_maxpool3x3s2_split32(const float* in, float* out, int n, int h, int w, int c, int out_ld,
                              int out_h, int out_w, fcp_stream_t stream);
+/* RetinaFace stem in one launch (precision 1): uint8 RGB image -> (x - mean_rgb) -> 7x7 / stride 2 / pad 3
+ * conv to 64 channels (BatchNorm folded into wfrag / bias) -> ReLU -> MaxPool2d(3, 2, 1), written as a 64-channel
+ * slice (out_ld elements per pixel) of an fp32 (out_fmt 0) or split32 (1) NHWC tensor of size
+ * (n, hp, wp) with hs = (h-1)/2+1, hp = (hs-1)/2+1.  Replaces retinaface.py:450-451 + the torchvision ResNet
+ * stem (conv1, bn1, relu, maxpool; retinaface.py:93-99).  x - mean is integral, hence exact in binary16: the
+ * fp16x3 product needs only a*wh + a*wl.  wfrag: the filter split hi / lo in MFMA fragment order
+ * [2 column tiles][11 k-steps][hi, lo][64 lanes][8 binary16], K index = kh*24 + kw*3 + c (RGB), zero-padded
+ * (engine.py::pack_stem_fused); wscale: the per-filter power-of-two scale.  mean_rgb: 3 integers in 0..255 (host). */
+int fcp_stem7x7s2_relu_pool_u8(const uint8_t* images, int n, int h, int w, const int32_t* mean_rgb,
+                               const void* wfrag, const float* bias, const float* wscale, float* out,
+                               int out_ld, int out_fmt, fcp_stream_t stream);
 /* Format converters between fp32 NHWC and split32 (npix pixels of c channels, c % 32 == 0). */
 int fcp_f32_to_split32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream);
 int fcp_split32_to_f32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream);

@@ -313,3 +313,35 @@ def test_conv_halo_tiles(cin, cout, hw, n, device, precision):
         assert (got[:, 64:] - ref2).abs().max().item() <= _tol(ref2) and got[:, :64].abs().max().item() == 0
     with pytest.raises(RuntimeError, match="halo-tile"):
         E.conv(E.pack_conv(torch.randn(64, cin, 3, 3), None, None, 1, 1, device), xs, tile_m=1, tile_n=64)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 77, 91), (1, 64, 64), (3, 50, 130), (1, 9, 200), (2, 640, 640)])
+def test_fused_stem_pool(n, h, w, device, precision):
+    """uint8 -> (x - mean) -> 7x7/2 conv + BN + ReLU -> max-pool 3x3/2 in one launch (RetinaFace stem, fp16x3 path):
+    vs torch fp32 ops; odd sizes, partial patches, image borders, both output formats, slice output."""
+    if precision != "f16x3":
+        pytest.skip("the fused stem belongs to the fp16x3 path")
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(n * 1000 + h + w)
+    img = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 12
+    bn = {"weight": torch.rand(64, generator=g) + 0.5, "bias": torch.randn(64, generator=g) * 0.1,
+          "running_mean": torch.randn(64, generator=g) * 0.1, "running_var": torch.rand(64, generator=g) + 0.5}
+    mean = (123, 117, 104)
+    x = img.permute(0, 3, 1, 2).float() - torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)
+    y = F.conv2d(x, wt, None, 2, 3)
+    y = F.batch_norm(y, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5)
+    ref = F.max_pool2d(F.relu(y), 3, 2, 1)
+    ps = E.pack_stem_fused(wt, bn, device)
+    out = E.stem_relu_pool_u8(ps, img.to(device), mean_rgb=mean, out_fmt=0)
+    assert out.fmt == 0 and tuple(out.nchw().shape) == tuple(ref.shape)
+    assert (out.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+    wide = E.Act.empty(n, ref.shape[2], ref.shape[3], 128, device, 1)
+    wide.buf.zero_()
+    E.stem_relu_pool_u8(ps, img.to(device), wide.slice(64, 64), mean_rgb=mean)
+    got = wide.nchw().cpu()
+    assert (got[:, 64:] - ref).abs().max().item() <= _tol(ref) and got[:, :64].abs().max().item() == 0
+    # same thing through the separate kernels of the generic path
+    pc = E.pack_conv(wt, None, bn, 2, 3, device)
+    sep = E.maxpool3x3s2(E.conv(pc, E.u8_to_nhwc4(img.to(device), sub=mean), act_slope=0.0, out_fmt=1))
+    assert (sep.nchw().cpu() - out.nchw().cpu()).abs().max().item() <= _tol(ref)

@@ -47,8 +47,9 @@ def test_predict_matches_reference_golden(strat, thr, sd, device):
     assert idx == d[f"pred_{strat}_{thr}_indices"].tolist()
     assert lm.dtype == np.float32 and lm.shape == d[f"pred_{strat}_{thr}_landmarks"].shape
     assert np.abs(lm - d[f"pred_{strat}_{thr}_landmarks"]).max() < 1e-3
-    lm2, idx2 = det.predict(torch.from_numpy(d["image"]))   # uint8 NHWC fast path
-    assert idx2 == idx and np.array_equal(lm, lm2)
+    lm2, idx2 = det.predict(torch.from_numpy(d["image"]))   # uint8 NHWC fast path (fp16x3: fused stem + pool kernel,
+    assert idx2 == idx                                      # i.e. another summation order in the first layer)
+    assert np.abs(lm2 - d[f"pred_{strat}_{thr}_landmarks"]).max() < 1e-3 and np.abs(lm - lm2).max() < 1e-3
 
 
 def test_predict_vs_oracle_nonsquare_with_padding(sd, device):
