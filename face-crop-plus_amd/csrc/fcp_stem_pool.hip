@@ -9,14 +9,17 @@
 // a power of two and split hi + lo offline, like every other filter of the fp16x3 path), accumulated in
 // fp32 — the same accuracy class as the generic kernels, with a different (kh, kw*3+c) summation order.
 //
-// Mapping.  A persistent workgroup (4 waves, one per SIMD) walks patches of 6 x 16 pooled pixels.  A patch
-// needs 13 x 33 stem pixels (14 MFMA row tiles of 32) from a 31 x 71 pixel image patch, which is staged in LDS
-// as raw bytes (out-of-image bytes = the channel mean, i.e. the conv's zero padding).  K = 7 filter rows x 24
-// (21 = 7 taps x 3 channels, padded): a lane's 8 consecutive K values are 8 consecutive bytes of one image
-// row, converted to binary16 with two byte-permutes (0x6400 | b = 1024 + b) and one packed subtract.  All 44
-// filter fragments (2 column tiles x 11 k-steps x hi/lo) live in registers for the lifetime of the workgroup.
-// The stem tile goes to LDS as fp32 (bias, ReLU, -inf outside the stem map = the pool's padding), is
-// max-pooled there and leaves as 16-byte stores.
+// Mapping.  A persistent workgroup of 8 waves (two per SIMD) walks patches of 5 x 16 pooled pixels.  A patch
+// needs 11 x 33 stem pixels (12 MFMA row tiles of 32) from a 27 x 71 pixel image patch.  The patch is fetched as
+// bytes (branch-free, clamped addresses, one patch ahead so the loads fly under the MFMAs), converted ONCE to
+// binary16 (x - mean; 0 outside the image = the conv's zero padding) and staged in LDS.  K = 7 filter rows x 24
+// (21 = 7 taps x 3 channels, padded): a lane's 8 consecutive K values are 8 consecutive binary16 of one staged
+// row, i.e. the MFMA fragment is four aligned dword reads with no arithmetic.  Wave w owns column tile w & 1
+// (32 filters; its 22 fragments = 11 k-steps x hi / lo stay in registers for the whole kernel) and the row tiles
+// (w >> 1) + 4k.  Raw accumulators go to LDS as fp32; the 3 x 3 / 2 max is taken there over the pixels inside the
+// stem map and scale, bias and ReLU — monotone per channel, so they commute with the max — are applied to the
+// 80 pooled pixels only, which leave as 16-byte stores.  Barriers order LDS traffic only (s_waitcnt lgkmcnt(0) +
+// s_barrier): neither the output stores nor the prefetch are drained at a barrier.
 #include "fcp_conv_common.h"
 
 using namespace fcp_conv;
@@ -26,16 +29,16 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int PH = 4, PW = 16;                 // pooled pixels per patch
-constexpr int SH = 2 * PH + 1, SW = 2 * PW + 1;  // stem pixels per patch: 9 x 33
-constexpr int NSTEM = SH * SW;                 // 297
-constexpr int NTILES = (NSTEM + 31) / 32;      // 10
-constexpr int IH = 2 * SH + 5;                 // 23 image rows (+1 spare row for the padded K chunk)
+constexpr int PH = 5, PW = 16;                 // pooled pixels per patch
+constexpr int SH = 2 * PH + 1, SW = 2 * PW + 1;  // stem pixels per patch: 11 x 33
+constexpr int NSTEM = SH * SW;                 // 363
+constexpr int NTILES = (NSTEM + 31) / 32;      // 12 = 3 per row-tile group
+constexpr int IH = 2 * SH + 5;                 // 27 image rows (+1 spare row for the padded K chunk)
 constexpr int IWB = (2 * SW + 5) * 3;          // 213 bytes per image row of the patch
 constexpr int IPITCH = 216;                    // binary16 elements per staged image row
-constexpr int IN_ELEMS = (IH + 1) * IPITCH;    // 5184 halves = 10 368 B
+constexpr int IN_ELEMS = (IH + 1) * IPITCH;    // 6048 halves = 12 096 B
 constexpr int NT = 512;                         // 8 waves: (row-tile group 0..3) x (column tile 0..1)
-constexpr int NLOAD = (IH * IWB + NT - 1) / NT;  // 10 bytes per thread
+constexpr int NLOAD = (IH * IWB + NT - 1) / NT;  // 12 bytes per thread
 constexpr int SPITCH = 68;                     // floats per staged stem pixel (64 + 4: conflict-free pooling)
 constexpr int KSTEPS = 11;                     // 22 chunks of 8 K values (7 rows x 3 chunks, +1 zero chunk)
 
@@ -120,7 +123,7 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
       const bool ok = (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
       pre_ok |= ok ? (1u << i) : 0u;
       const int yc = min(max(y, 0), p.h - 1), xc = min(max(x, 0), p.w - 1);
-      pre[i] = base[((long)yc * p.w + xc) * 3 + (lcol[i] - lxc[i] * 3)];
+      pre[i] = base[(unsigned)((yc * p.w + xc) * 3 + (lcol[i] - lxc[i] * 3))];
     }
   };
   auto commit = [&]() {
@@ -235,7 +238,7 @@ extern "C" int fcp_stem7x7s2_relu_pool_u8(const uint8_t* images, int n, int h, i
                                           const void* wfrag, const float* bias, const float* wscale, float* out,
                                           int out_ld, int out_fmt, fcp_stream_t stream) {
   FCP_REQUIRE(images && wfrag && bias && wscale && out && mean_rgb, "stem: null pointer");
-  FCP_REQUIRE(n > 0 && h >= 1 && w >= 1, "stem: bad image size");
+  FCP_REQUIRE(n > 0 && h >= 1 && w >= 1 && (long)h * w * 3 < (1L << 31), "stem: bad image size");
   FCP_REQUIRE((unsigned)out_fmt <= 1u, "stem: out_fmt must be 0 (fp32) or 1 (split32)");
   FCP_REQUIRE(out_ld >= 64 && out_ld % (out_fmt ? 32 : 4) == 0 && ((uintptr_t)out & (out_fmt ? 127 : 15)) == 0,
               "stem: misaligned output view");
