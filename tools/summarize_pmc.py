@@ -16,22 +16,28 @@ def load(path):
     d = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
         d.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"]})[r["Counter_Name"]] = float(r["Counter_Value"])
-    return [v for v in d.values() if "conv_igemm" in v["name"]][-LAUNCHES:]
+    return [v for v in d.values() if any(k in v["name"] for k in ("conv_igemm", "conv3x3_halo", "stem_pool_kernel"))][-LAUNCHES:]
 
 
 import glob
 f, w, s = (load(glob.glob(f"{src}/{k}/**/*counter_collection.csv", recursive=True)[0]) for k in ("fetch", "write", "sq"))
 fetch_kib = sum(v["FETCH_SIZE"] for v in f)
 write_kib = sum(v["WRITE_SIZE"] for v in w)
-stem_expected_kib = 64 * 640 * 640 * 16 / 1024          # NHWC4 fp32 input of the batch-64 640^2 stem
+# Calibration launch with an exactly known read size.  fp32 path: the stem conv reads the NHWC4 fp32 batch once.
+# fp16x3 path (fused uint8 stem, whose byte loads and halo re-reads are not "wide coalesced reads"): the next
+# launch, layer1.0.conv1, reads the pooled 64-channel stem map (64 x 160 x 160 x 64 x 4 B) once.
+fused = "stem_pool_kernel" in f[0]["name"]
+cal = 1 if fused else 0
+stem_expected_kib = (64 * 160 * 160 * 64 * 4 if fused else 64 * 640 * 640 * 16) / 1024
 read_corr = 2.0
 mfma_busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in s)
 gui = sum(v["GRBM_GUI_ACTIVE"] for v in s)               # summed over the 8 XCDs
 out = {
     "command": f"bench.py --steps 1 --warmup 1 --no-cpu-baseline (batch 64, 640x640), last step's {LAUNCHES} conv launches",
     "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
-    "fetch_calibration": {"stem_reported_kib": f[0]["FETCH_SIZE"], "stem_expected_kib": stem_expected_kib,
-                          "ratio": f[0]["FETCH_SIZE"] / stem_expected_kib, "correction_applied": read_corr},
+    "fetch_calibration": {"launch": f[cal]["name"][:60], "reported_kib": f[cal]["FETCH_SIZE"],
+                          "expected_kib": stem_expected_kib, "ratio": f[cal]["FETCH_SIZE"] / stem_expected_kib,
+                          "correction_applied": read_corr},
     "hbm_bytes_per_step": (fetch_kib * read_corr + write_kib) * 1024,
     "hbm_bytes_per_launch": (fetch_kib * read_corr + write_kib) * 1024 / LAUNCHES,
     "mfma_busy_cycles": mfma_busy, "grbm_gui_active_sum_8xcd": gui,
