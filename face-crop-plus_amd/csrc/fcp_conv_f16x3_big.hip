@@ -45,8 +45,106 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// Rows [crow + g*RPP] of a staged 256 x 128 fp32 tile -> fused epilogue, 8 channels per lane.
-__device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, int tile_m, int co_base, int tid, int hw) {
+// Epilogue of one 256 x 128 half tile, 8 channels per lane, in two steps so that no lane ever waits for a single
+// load: (1) all residual rows of the half tile are requested at once, branch-free (clamped addresses), BEFORE the
+// accumulators are staged; (2) rows [crow + g*RPP] of the staged fp32 tile are combined with them and stored.  (A
+// per-row "if in range: load, use" loop compiles to one exposed HBM round trip per row.)
+constexpr int E_CPR = 128 / 8, E_RPP = NT / E_CPR, E_PASSES = BMB / E_RPP;   // 16 lanes per row, 32 rows per pass, 8 passes
+
+template <int NP>
+struct ResRows {
+  u32x4_t a[NP], b[NP];     // split32: hi, lo chunks; fp32: channels c..c+3, c+4..c+7
+};
+
+// passes [g0, g0 + NP) of the half tile
+template <int NP>
+__device__ __forceinline__ void load_res1_rows(const ConvK& p, int tile_m, int co_base, int tid, int hw, int g0, ResRows<NP>& r) {
+  int co = co_base + (tid % E_CPR) * 8;
+  co = co < p.cout ? co : 0;                                     // inactive lanes read a valid dummy
+  const long m0 = (long)tile_m * BMB + tid / E_CPR;
+#pragma unroll
+  for (int g = 0; g < NP; ++g) {
+    long m = m0 + (long)(g0 + g) * E_RPP;
+    m = m < p.M ? m : (long)p.M - 1;
+    long rpix = m;
+    if (p.res1_resize) {
+      const int ni = (int)(m / hw);
+      const int rem = (int)(m - (long)ni * hw);
+      const int ho = rem / p.out_w;
+      const int wo = rem - ho * p.out_w;
+      int sh = (int)floorf(ho * p.res1_sh);
+      int sw = (int)floorf(wo * p.res1_sw);
+      sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
+      sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
+      rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
+    }
+    const char* pb = reinterpret_cast<const char*>(p.res1) + rpix * p.res1_ld * 4 +
+                     (p.res1_fmt == 1 ? split_chan_off(co) : (long)co * 4);
+    r.a[g] = *reinterpret_cast<const u32x4_t*>(pb);
+    r.b[g] = *reinterpret_cast<const u32x4_t*>(pb + (p.res1_fmt == 1 ? 64 : 16));
+  }
+}
+
+template <int NP>
+__device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, int tile_m, int co_base, int tid, int hw,
+                                              int g0, const ResRows<NP>& res) {
+  const int ccol = (tid % E_CPR) * 8;
+  const int crow = tid / E_CPR;
+  const int co = co_base + ccol;
+  if (co >= p.cout) return;
+  const long m0 = (long)tile_m * BMB + crow;
+  float bias8[8], ws8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bias8[e] = p.bias != nullptr ? p.bias[co + e] : 0.f;
+    ws8[e] = p.wscale[co + e];
+  }
+#pragma unroll
+  for (int g = 0; g < NP; ++g) {
+    const int row = crow + (g0 + g) * E_RPP;
+    const long m = m0 + (long)(g0 + g) * E_RPP;
+    float v[8], r1[8], r2[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * 128 + ccol);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * 128 + ccol + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+    if (p.res1 != nullptr) {
+      if (p.res1_fmt == 1) {
+        join8(res.a[g], res.b[g], r1);
+      } else {
+        const f32x4 fa = __builtin_bit_cast(f32x4, res.a[g]), fb = __builtin_bit_cast(f32x4, res.b[g]);
+        r1[0] = fa[0]; r1[1] = fa[1]; r1[2] = fa[2]; r1[3] = fa[3]; r1[4] = fb[0]; r1[5] = fb[1]; r1[6] = fb[2]; r1[7] = fb[3];
+      }
+    }
+    if (p.res2 != nullptr && m < p.M) load8(p.res2, m, p.res2_ld, co, p.res2_fmt, r2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = v[e] * ws8[e] + bias8[e];
+      if (p.res1 != nullptr && p.res1_pre) x += r1[e];
+      x = x >= 0.f ? x : x * p.act_slope;
+      x = x * p.alpha;
+      if (p.res1 != nullptr && !p.res1_pre) x += r1[e];
+      if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
+      v[e] = x;
+    }
+    if (m >= p.M) continue;
+    if (p.out_fmt == 1) {
+      u32x4_t hi, lo;
+      split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+      char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + split_chan_off(co);
+      *reinterpret_cast<u32x4_t*>(ob) = hi;
+      *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
+    } else {
+      float* dst = p.out + m * p.out_ld + co;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+}
+
+// Row-at-a-time variant (no extra registers): used by the 256-column tile, whose main loop has none to spare.
+__device__ __forceinline__ void epilogue_rows_seq(const ConvK& p, const float* Cs, int tile_m, int co_base, int tid, int hw) {
   constexpr int CPR = 128 / 8, RPP = NT / CPR, PASSES = BMB / RPP;
   const int ccol = (tid % CPR) * 8;
   const int crow = tid / CPR;
@@ -309,6 +407,11 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   float* Cs = smem;
 #pragma unroll 1
   for (int h = 0; h < BN / 128; ++h) {
+    // The 128-column tile requests all residual rows of the half tile at once, before staging the accumulators.
+    // The 256-column tile has no registers to spare (254 live in its main loop; any more and the allocator spills
+    // there), so it keeps the row-at-a-time epilogue: it is the kernel of the residual-free layers.
+    ResRows<E_PASSES> res;
+    if (BN == 128 && p.res1 != nullptr) load_res1_rows<E_PASSES>(p, tile_m, tile_n * BN + h * 128, tid, hw, 0, res);
     if ((wn * WTN) / 128 == h) {
       const int cbase = wn * WTN - h * 128;
 #pragma unroll
@@ -322,7 +425,10 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
           }
     }
     __syncthreads();
-    epilogue_rows(p, Cs, tile_m, tile_n * BN + h * 128, tid, hw);
+    if constexpr (BN == 128)
+      epilogue_rows<E_PASSES>(p, Cs, tile_m, tile_n * BN + h * 128, tid, hw, 0, res);
+    else
+      epilogue_rows_seq(p, Cs, tile_m, tile_n * BN + h * 128, tid, hw);
     __syncthreads();
   }
 }
