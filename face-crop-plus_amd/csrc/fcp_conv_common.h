@@ -42,6 +42,7 @@ struct ConvK {
   const float* in2;
   unsigned in2_bytes;
   int csplit, in2_ld, ph2, pw2, stride2;
+  int nt_store;   // 1: split32 outputs are written with non-temporal (streaming) stores
 };
 
 
@@ -356,8 +357,13 @@ __device__ __forceinline__ void conv_epilogue8(const ConvK& p, f32x16 (&acc)[TM]
       u32x4_t hi, lo;
       split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
       char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + split_chan_off(co);
-      *reinterpret_cast<u32x4_t*>(ob) = hi;
-      *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
+      if (p.nt_store) {
+        __builtin_nontemporal_store(hi, reinterpret_cast<u32x4_t*>(ob));
+        __builtin_nontemporal_store(lo, reinterpret_cast<u32x4_t*>(ob + 64));
+      } else {
+        *reinterpret_cast<u32x4_t*>(ob) = hi;
+        *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
+      }
     } else {
       float* dst = p.out + m * p.out_ld + co;
       *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
