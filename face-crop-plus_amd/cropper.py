@@ -8,7 +8,6 @@ from __future__ import annotations
 
 import os
 from collections import defaultdict
-from functools import partial
 from multiprocessing.pool import ThreadPool
 from threading import Lock, local
 

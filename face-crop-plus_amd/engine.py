@@ -6,7 +6,9 @@ call goes through ``libfcp_hip.so``.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -93,9 +95,6 @@ def fold_bn(weight: np.ndarray, bn: dict | None, bias: np.ndarray | None):
         beta = (beta + np.asarray(bias, f) * alpha).astype(f)
     return (w * alpha[:, None, None, None]).astype(f), beta
 
-
-import contextlib
-import os
 
 PRECISIONS = {"f32": 0, "fp32": 0, "exact": 0, 0: 0, "f16x3": 1, "fp16x3": 1, 1: 1}
 # module-wide default for pack_conv(precision=None): env FCP_PRECISION = f32 | f16x3

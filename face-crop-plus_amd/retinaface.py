@@ -12,7 +12,6 @@ data path touches the host before the final landmark copy.
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import os
 
