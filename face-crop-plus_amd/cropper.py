@@ -16,7 +16,7 @@ import torch
 
 from . import align
 from .batch import build_batch
-from .utils import get_ldm_slices, parse_landmarks_file, read_images, write_image
+from .utils import get_ldm_slices, parse_landmarks_file, read_image, read_images, write_image
 
 
 def landmarks_target(output_size, face_factor):
@@ -281,18 +281,27 @@ class Cropper:
         depth = max(2, 2 * self.num_processes)
         io = ThreadPoolExecutor(max_workers=self.io_threads, thread_name_prefix="fcp-io")
         self._writer, self._writes = io, []
-        reads = {i: io.submit(read_images, file_batches[i], input_dir) for i in range(min(depth, len(file_batches)))}
+        # every file is its own decode task (a batch decoded by one thread would cap the pipeline at `depth` decoders)
+        def submit_read(i):
+            return [io.submit(read_image, os.path.join(input_dir, f)) for f in file_batches[i]]
+
+        def collect_read(i, futs):
+            decoded = [f.result() for f in futs]
+            ok = [k for k, im in enumerate(decoded) if im is not None]
+            return [decoded[k] for k in ok], np.array(file_batches[i])[ok]
+
+        reads = {i: submit_read(i) for i in range(min(depth, len(file_batches)))}
         lock = Lock()
 
         tls = local()
 
         def worker(i):
-            fut = reads.pop(i, None)
-            images, names = fut.result() if fut is not None else read_images(file_batches[i], input_dir)
+            futs = reads.pop(i, None)
             with lock:
                 nxt = i + depth
                 if nxt < len(file_batches) and nxt not in reads:
-                    reads[nxt] = io.submit(read_images, file_batches[nxt], input_dir)
+                    reads[nxt] = submit_read(nxt)
+            images, names = collect_read(i, futs) if futs is not None else read_images(file_batches[i], input_dir)
             if self.num_processes == 1:
                 return self._process_images(images, names, output_dir)
             # one HIP stream per GPU worker: the batches of different workers overlap on the device (the tail of

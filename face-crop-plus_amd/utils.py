@@ -58,22 +58,25 @@ def get_ldm_slices(num_tgt_landmarks: int, num_src_landmarks: int):
     return get_landmark_slices_5(num_src_landmarks)
 
 
-def read_images(file_names, input_dir):
-    """-> (list of RGB uint8 HWC arrays, ndarray of surviving file names); unreadable
-    files warn and are skipped (utils.py:228-271)."""
+def read_image(path: str):
+    """One file -> RGB uint8 HWC array, or None (with the reference's warning) when it cannot be read."""
     from PIL import Image
-    indices, images = [], []
-    for i, file_name in enumerate(file_names):
-        path = os.path.join(input_dir, file_name)
-        try:
-            with Image.open(path) as im:
-                image = np.asarray(im.convert("RGB"), dtype=np.uint8)
-        except Exception:
-            warnings.warn(f"Could not read the image {path}")
-            continue
-        images.append(image)
-        indices.append(i)
-    return images, np.array(file_names)[indices]
+    try:
+        with Image.open(path) as im:
+            return np.asarray(im.convert("RGB"), dtype=np.uint8)
+    except Exception:
+        warnings.warn(f"Could not read the image {path}")
+        return None
+
+
+def read_images(file_names, input_dir, pool=None):
+    """-> (list of RGB uint8 HWC arrays, ndarray of surviving file names); unreadable files warn and are
+    skipped (utils.py:228-271).  ``pool``: optional executor decoding the files concurrently (Pillow releases
+    the GIL while decoding); the result order is the input order either way."""
+    paths = [os.path.join(input_dir, f) for f in file_names]
+    decoded = list(pool.map(read_image, paths)) if pool is not None else [read_image(p) for p in paths]
+    indices = [i for i, im in enumerate(decoded) if im is not None]
+    return [decoded[i] for i in indices], np.array(file_names)[indices]
 
 
 def as_batch(images, size=512, padding_mode: str = "constant", device="cuda:0"):
