@@ -380,8 +380,13 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
     k.in_bytes = (unsigned)in_bytes;
     k.w_bytes = (unsigned)w_bytes;
     // split32 activations: both operands are pure byte copies -> LDS-DMA kernel
-    static const int dma_env = getenv("FCP_CONV_DMA") ? atoi(getenv("FCP_CONV_DMA")) : 2;   // 0 off, 2 / 3 = LDS stages
-    FCP_REQUIRE(!k.in2 || big || dma_env, "conv: a second source needs the LDS-DMA kernels (FCP_CONV_DMA != 0)");
+    // two LDS stages (three were measured slower: they cost an occupancy step); profiling builds may override
+#ifdef FCP_CONV_PROFILING
+    static const int dma_env = getenv("FCP_CONV_DMA") ? atoi(getenv("FCP_CONV_DMA")) : 2;
+    const int dma_stages = dma_env == 3 ? 3 : 2;
+#else
+    const int dma_stages = 2;
+#endif
     if (halo) {
       k.w_bytes = (unsigned)((unsigned long)fcp_cdiv(d->cout, 128) * 128ul * k.wrow * 4ul);
       return launch_f16x3_halo(k, s);
@@ -390,7 +395,7 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
       k.w_bytes = (unsigned)((unsigned long)fcp_cdiv(d->cout, 128) * 128ul * k.wrow * 4ul);   // filters are padded to 128 rows
       return launch_f16x3_big(k, d->tile_n, s);
     }
-    if (k.in_fmt == 1 && !d->cin4 && dma_env) return launch_f16x3_dma(k, d->tile_n, dma_env, s);
+    if (k.in_fmt == 1 && !d->cin4) return launch_f16x3_dma(k, d->tile_n, dma_stages, s);
     return launch_f16x3(k, d->tile_n, d->cin4 != 0, s);
   }
   k.in_bytes = buf ? (unsigned)in_bytes : 0u;
