@@ -57,3 +57,22 @@ def test_graft_entry_build_in_a_fresh_interpreter():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); print('ok')"], cwd=root,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: importing every product module (incl. the CLI) must not pull it in, and
+    no product source may mention it."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, importlib\n"
+            "for m in ('cropper','retinaface','rrdb','bise','align','batch','utils','engine','weights','dist','__main__','_native'):\n"
+            "    importlib.import_module('face_crop_plus_amd.' + m)\n"
+            "bad = [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]\n"
+            "assert not bad, bad\nprint('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+    pkg = os.path.join(root, "face-crop-plus_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
