@@ -345,3 +345,48 @@ def test_fused_stem_pool(n, h, w, device, precision):
     pc = E.pack_conv(wt, None, bn, 2, 3, device)
     sep = E.maxpool3x3s2(E.conv(pc, E.u8_to_nhwc4(img.to(device), sub=mean), act_slope=0.0, out_fmt=1))
     assert (sep.nchw().cpu() - out.nchw().cpu()).abs().max().item() <= _tol(ref)
+
+
+def test_conv_randomized_shapes(device, precision):
+    """Seeded sweep over geometry / epilogue / format combinations (every tile the shape admits) against torch fp32."""
+    from face_crop_plus_amd import engine as E
+    rng = np.random.default_rng(2024)
+    f16 = precision == "f16x3"
+    for it in range(36):
+        k = int(rng.choice([1, 3, 5]))
+        stride = int(rng.choice([1, 2]))
+        pad = int(rng.choice([0, k // 2]))
+        cin = int(rng.choice([32, 64, 96, 160, 256]))
+        cout = int(rng.choice([8, 24, 32, 64, 72, 128, 192, 256, 320]))
+        n = int(rng.integers(1, 4))
+        h, w = int(rng.integers(k, 40)), int(rng.integers(k, 40))
+        g = torch.Generator().manual_seed(it)
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        b = torch.randn(cout, generator=g) if rng.random() < 0.7 else None
+        ref = F.conv2d(x, wt, b, stride, pad)
+        use_res, pre, slope, alpha = rng.random() < 0.5, bool(rng.random() < 0.5), float(rng.choice([0.0, 0.2, 1.0])), float(rng.choice([1.0, 0.2]))
+        res = torch.randn(*ref.shape, generator=g) if use_res else None
+        y = ref + res if (use_res and pre) else ref
+        y = F.leaky_relu(y, slope) * alpha
+        y = y + res if (use_res and not pre) else y
+        pc = E.pack_conv(wt, b, None, stride, pad, device)
+        split_in = f16 and bool(rng.random() < 0.7)
+        split_out = f16 and cout % 32 == 0 and bool(rng.random() < 0.5)
+        xa = E.Act(_nhwc(x, device))
+        xa = E.f32_to_split32(xa) if split_in else xa
+        ra = None
+        if use_res:
+            ra = E.Act(_nhwc(res, device))
+            ra = E.f32_to_split32(ra) if (f16 and cout % 32 == 0 and rng.random() < 0.5) else ra
+        tiles = [(128, 32), (128, 64), (128, 128)]
+        if split_in and cout % 8 == 0:
+            tiles += [(256, 128), (256, 256)]
+            if (k, stride, pad) == (3, 1, 1) and cout <= 32:
+                tiles.append((1, 32))
+        if (split_in or split_out or (ra is not None and ra.fmt)) and cout % 8:
+            continue                                              # split32 epilogue needs cout % 8 == 0
+        for tm, tn in tiles:
+            out = E.conv(pc, xa, act_slope=slope, alpha=alpha, res1=ra, res1_pre=pre, out_fmt=int(split_out), tile_m=tm, tile_n=tn)
+            err = (out.nchw().cpu() - y).abs().max().item()
+            assert err <= _tol(y) * (3 if not f16 else 1) + 1e-6, (it, k, stride, pad, cin, cout, n, h, w, tm, tn, err)
