@@ -161,3 +161,22 @@ def test_process_dir_pipeline_is_deterministic(tmp_path, device):
             c.process_batch(files[i:i + 3], str(src), str(tmp_path / "sync"))
     outs.append({f: (tmp_path / "sync" / f).read_bytes() for f in sorted(os.listdir(tmp_path / "sync"))})
     assert len(outs[0]) > 5 and outs[0] == outs[1] == outs[2]
+
+
+def test_crop_align_plumbing_like_reference(device):
+    """The semantics recorded from the reference's crop_align with a stand-in cv2 (tests/golden/plumbing.json):
+    output (F, h, w, 3) for output_size = (w, h); the padded band of a batch image is never sampled
+    (image[t:h-b, l:w-r] is the warp source); reflect border; empty input -> empty array."""
+    from face_crop_plus_amd import Cropper
+    c = Cropper(output_size=(96, 112), padding="reflect", det_threshold=None, device="cuda:0")
+    images = np.stack([np.full((40, 60, 3), v, np.uint8) for v in (10, 20, 30)])
+    paddings = np.array([[0, 0, 0, 0], [3, 4, 0, 0], [0, 0, 5, 6]])
+    images[1, :3], images[1, 36:], images[2, :, :5], images[2, :, 54:] = 255, 255, 255, 255      # paint the bands
+    tgt = c.landmarks_target
+    lms = np.stack([tgt * 0.3 + 5, tgt * 0.25 + 2, tgt * 0.2 + 1, tgt * 0.3 + 3, tgt * 0.3 + 20]).astype(np.float32)
+    out = c.crop_align(images, paddings, [0, 1, 1, 2, 2], lms)
+    assert out.shape == (5, 112, 96, 3) and out.dtype == np.uint8
+    assert [int(np.unique(o)[0]) for o in out] == [10, 20, 20, 30, 30] and all(len(np.unique(o)) == 1 for o in out)
+    assert c.crop_align(images, paddings, [], lms[:0]).shape == (0,)
+    lms[1] = 7.0                                                    # all five points coincide: no transform -> face dropped
+    assert c.crop_align(images, paddings, [0, 1, 1], lms[:3]).shape == (2, 112, 96, 3)

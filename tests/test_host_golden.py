@@ -89,3 +89,70 @@ def test_clean_names_matches_reference(tmp_path, monkeypatch):
     utils.clean_names(str(src), str(tmp_path / "short"), max_chars=len(str(src)) + g["short_max_chars_extra"], desc=None)
     got = {str((tmp_path / "short" / n).read_bytes()[0]): n for n in real_listdir(tmp_path / "short")}
     assert got == g["short"]
+
+
+@pytest.fixture(scope="module")
+def plumb():
+    return json.load(open(os.path.join(G, "plumbing.json")))
+
+
+def test_batch_geometry_matches_reference_as_batch_calls(plumb):
+    """What the reference asks OpenCV for inside as_batch (utils.py:316-335), recorded with a stand-in cv2:
+    resize target, interpolation constant, border widths, un-scale factors, batch shape."""
+    from face_crop_plus_amd.batch import batch_geometry
+    from face_crop_plus_amd.align import border_code
+    from oracle import batch_ref
+    for key, rec in plumb.items():
+        if not key.startswith("as_batch_") or key == "as_batch_border_mode":
+            continue
+        size = eval(key[len("as_batch_"):])
+        size = (size, size) if isinstance(size, int) else tuple(size)
+        calls = rec["calls"]
+        assert rec["batch_shape"] == [len(rec["shapes"]), size[1], size[0], 3]
+        for i, (h, w) in enumerate(rec["shapes"]):
+            rz, mb = calls[2 * i], calls[2 * i + 1]
+            ww, hh, pad, unscale, interp = batch_geometry(h, w, size)
+            assert rz[0] == "resize" and rz[1] == [h, w, 3] and rz[2] == [ww, hh], (key, h, w)
+            assert rz[3] == (3 if interp == 1 else 2)                       # cv2.INTER_AREA = 3, cv2.INTER_CUBIC = 2
+            assert mb[0] == "copyMakeBorder" and mb[1] == [hh, ww, 3] and mb[2] == pad == rec["paddings"][i] and mb[3] == 0
+            assert unscale == rec["unscales"][i]
+            assert batch_ref.geometry(h, w, size) == (ww, hh, pad, unscale, "area" if interp else "cubic")
+    assert plumb["as_batch_border_mode"][1][3] == border_code("reflect_101") == 4
+
+
+def test_save_group_paths_match_reference(plumb, tmp_path, monkeypatch):
+    """File naming / directory layout of save_group and save_groups (cropper.py:554-746): same paths, same order."""
+    import face_crop_plus_amd.cropper as CR
+    written = []
+    monkeypatch.setattr(CR, "write_image", lambda path, img: written.append(os.path.relpath(path, tmp_path)))
+    c = CR.Cropper.__new__(CR.Cropper)
+    c._writer = c._writes = None
+    faces = [np.zeros((4, 4, 3), np.uint8)] * 5 + [np.zeros((4, 4), np.uint8)]
+    names = np.array(["a.jpg", "a.jpg", "b.png", "a.jpg", "c.jpeg", "b.png"])
+    for strategy, fmt in (("all", None), ("largest", None), ("all", "png"), ("best", "jpg")):
+        written.clear()
+        c.strategy, c.output_format = strategy, fmt
+        c.save_group(faces, names, str(tmp_path / "o"))
+        assert written == [p[1] for p in plumb[f"save_group_{strategy}_{fmt}"] if p[0] == "imwrite"], (strategy, fmt)
+    c.strategy, c.output_format = "all", None
+    attr = {"glasses": [0, 2, 4], "no_glasses": [1, 3]}
+    masks = {"eyes": ([0, 1, 4], np.zeros((3, 4, 4), np.uint8)), "hair": ([2], np.zeros((1, 4, 4), np.uint8))}
+    for key, out, a, m in (("save_groups_attr_mask", "g", attr, masks), ("save_groups_none", "n", None, None),
+                           ("save_groups_mask_only", "m", None, masks)):
+        written.clear()
+        c.save_groups(faces[:5], names[:5], str(tmp_path / out), a, m)
+        assert written == plumb[key], key
+
+
+def test_crop_align_plumbing_constants(plumb):
+    """crop_align's OpenCV arguments (cropper.py:511-547): border constant, dsize = output_size as (w, h),
+    ransacReprojThreshold = inf, the un-padded source slice, estimator choice, skipped faces."""
+    from face_crop_plus_amd.align import border_code
+    calls = plumb["crop_align"]["calls"]
+    warps = [c for c in calls if c[0] == "warpAffine"]
+    assert all(c[5] == border_code("reflect") == 2 and c[4] == [96, 112] for c in warps)
+    assert [c[1] for c in warps] == [[40, 60, 3], [33, 60, 3], [40, 49, 3], [40, 49, 3]]     # image[t:h-b, l:w-r]
+    assert all(c[2] for c in calls if c[0].startswith("estimate"))                            # threshold is inf
+    assert plumb["crop_align"]["result_shape"] == [4, 112, 96, 3] and plumb["crop_align"]["result_values"] == [10, 20, 30, 30]
+    assert [c[0] for c in plumb["crop_align_skew_list_nopad"]["calls"]] == ["estimateAffine2D", "warpAffine"]
+    assert plumb["crop_align_empty"]["result_shape"] == [0]
