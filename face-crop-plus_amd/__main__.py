@@ -48,7 +48,7 @@ def parse_args(argv=None) -> dict:
     args = vars(parser.parse_args(argv))
     args.pop("config")
     if args["input_dir"] is None:
-        parser.error("the following arguments are required: -i/--input_dir")
+        raise ValueError("Input directory must be specified.")        # __main__.py:231-232 of the reference
     for k in ("det_threshold", "enh_threshold"):
         if args[k] is not None and args[k] < 0:
             args[k] = None

@@ -30,7 +30,7 @@ def test_config_file_supplies_defaults(tmp_path):
 
 def test_input_dir_is_required():
     from face_crop_plus_amd.__main__ import parse_args
-    with pytest.raises(SystemExit):
+    with pytest.raises(ValueError, match="Input directory must be specified"):
         parse_args([])
 
 

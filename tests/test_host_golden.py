@@ -156,3 +156,27 @@ def test_crop_align_plumbing_constants(plumb):
     assert plumb["crop_align"]["result_shape"] == [4, 112, 96, 3] and plumb["crop_align"]["result_values"] == [10, 20, 30, 30]
     assert [c[0] for c in plumb["crop_align_skew_list_nopad"]["calls"]] == ["estimateAffine2D", "warpAffine"]
     assert plumb["crop_align_empty"]["result_shape"] == [0]
+
+
+def test_cli_matches_reference_parser(tmp_path):
+    """Every flag, default, config-file override and threshold sentinel of the reference's own parser
+    (__main__.py:10-249, golden: tests/golden/cli.json).  One difference by design: "auto" resolves to this
+    rank's GPU ("cuda:<LOCAL_RANK>") instead of "cuda"."""
+    from face_crop_plus_amd.__main__ import parse_args
+    g = json.load(open(os.path.join(G, "cli.json")))
+    cfg = tmp_path / "cfg.json"
+    cfg.write_text(json.dumps(g["_config_file"]))
+    n = 0
+    for name, case in g.items():
+        if name.startswith("_"):
+            continue
+        argv = [str(cfg) if a == "<CFG>" else a for a in case["argv"]]
+        got, exp = parse_args(argv), dict(case["kwargs"])
+        if exp["device"] == "cuda":
+            assert got["device"] == f"cuda:{os.environ.get('LOCAL_RANK', '0')}"
+            exp["device"] = got["device"]
+        assert got == exp, (name, {k: (got.get(k), exp.get(k)) for k in set(got) | set(exp) if got.get(k) != exp.get(k)})
+        n += 1
+    assert n >= 7 and g["_no_input"] == "ValueError"
+    with pytest.raises(ValueError):
+        parse_args([])
