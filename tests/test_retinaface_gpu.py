@@ -102,3 +102,16 @@ def test_graph_replay_matches_eager(sd, device):
         assert torch.equal(res["img_idx"][:nf], eager["img_idx"][:nf])
     with pytest.raises(ValueError):
         RetinaFace("all", 0.6).load(device, sd).graphed(1, 64, 64)
+
+
+@pytest.mark.parametrize("hw", [(1, 1), (8, 8), (17, 23), (33, 65), (640, 8)])
+def test_degenerate_image_sizes_vs_oracle(hw, sd, device):
+    """Edge geometries (smaller than one stride-32 cell, one pixel, extreme aspect): same faces as the oracle."""
+    from face_crop_plus_amd.retinaface import RetinaFace
+    from oracle import retinaface_ref as R
+    h, w = hw
+    g = torch.Generator().manual_seed(h * 100 + w)
+    img = torch.randint(0, 256, (2, h, w, 3), generator=g, dtype=torch.uint8)
+    lm, idx = RetinaFace("all", 0.5).load(device, sd).predict(img)
+    lr, ir = R.predict(img.permute(0, 3, 1, 2).float(), sd, "all", 0.5)
+    assert list(idx) == list(ir) and len(idx) > 0 and np.abs(lm - lr).max() < 2e-3
