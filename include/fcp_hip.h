@@ -54,11 +54,11 @@ const char* fcp_last_error(void);
  *   cin4 mode   : [cout_pad][kh][8][4]               cin <= 4, kw <= 8
  * precision 0 stores fp32; precision 1 stores, for every 32 consecutive K values of a
  * row, 32 binary16 hi parts followed by 32 binary16 lo parts (same 128 bytes).
- * cout_pad = cout rounded up to the N tile (32/64/128) chosen by `tile_n`;
+ * cout_pad = cout rounded up to a multiple of 128 (whatever N tile a launch uses);
  * the padding rows are zero.  BatchNorm (eval) is folded into w and bias.
  *
  * Epilogue (fp32, in this order):
- *   v = acc + bias[co]
+ *   v = acc * wscale[co] + bias[co]        (wscale = 1 for precision 0)
  *   if (res1 && res1_pre)  v += res1[...]
  *   v = v >= 0 ? v : v * act_slope        (act_slope = 1 -> identity, 0 -> ReLU)
  *   v = v * alpha
