@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_f32p = C.c_void_p
 _lib = None
@@ -33,8 +33,11 @@ class ConvDesc(C.Structure):
         ("res1_w", C.c_int32), ("res2_ld", C.c_int32), ("precision", C.c_int32),
         ("in_fmt", C.c_int32), ("out_fmt", C.c_int32), ("res1_fmt", C.c_int32), ("res2_fmt", C.c_int32),
         ("tile_m", C.c_int32), ("cin2", C.c_int32), ("in2_ld", C.c_int32), ("in2_h", C.c_int32),
-        ("in2_w", C.c_int32), ("in2_stride", C.c_int32),
+        ("in2_w", C.c_int32), ("in2_stride", C.c_int32), ("flags", C.c_int32),
     ]
+
+
+CONV_FLAT_ADDR = 1   # fcp_conv_desc.flags: FCP_CONV_FLAT_ADDR
 
 
 # name -> argtypes; every function returns int (0 = ok)

@@ -6,15 +6,16 @@ only the uint8 crops / masks it has to write to disk.
 """
 from __future__ import annotations
 
+import itertools
 import os
-from collections import defaultdict
+from collections import Counter, defaultdict
 from multiprocessing.pool import ThreadPool
-from threading import Lock, local
+from threading import BoundedSemaphore, Lock, local
 
 import numpy as np
 import torch
 
-from . import align
+from . import align, trace
 from .batch import build_batch
 from .utils import get_ldm_slices, parse_landmarks_file, read_image, read_images, write_image
 
@@ -75,7 +76,9 @@ class Cropper:
         # host I/O threads of process_dir (decode prefetch + asynchronous encode/write around the GPU workers)
         self.io_threads = max(2, min(16, (os.cpu_count() or 4) // 2))
         self._writer = None          # set by process_dir: executor the encoded files are written on
-        self._writes = None
+        self._writes = None          # futures of the writes still in flight
+        self._write_slots = None     # back-pressure: bounds the in-flight writes
+        self._write_lock = Lock()
 
         if isinstance(self.output_size, int):
             self.output_size = (self.output_size, self.output_size)
@@ -161,44 +164,85 @@ class Cropper:
         return np.stack(outs) if len(outs) > 0 else np.array(outs)
 
     # ----------------------------------------------------------------- saving
-    def save_group(self, faces, file_names, output_dir: str):
-        """cropper.py:554-609 (PIL writer; arrays are already RGB)."""
-        if len(faces) == 0:
-            return
-        os.makedirs(output_dir, exist_ok=True)
-        file_name_counts = defaultdict(lambda: -1)
-        for face, file_name in zip(faces, file_names):
-            name, ext = os.path.splitext(str(file_name))
+    MAX_PENDING_WRITES = 256     # encode / write tasks in flight before a GPU worker waits (process_dir)
+
+    def _target_paths(self, file_names, output_dir: str):
+        """Where each face of one group goes, in face order.  Naming rules of the reference's writer
+        (cropper.py:588-603): the source file's stem; with strategy "all" a running "_<k>" per source file,
+        counted inside this group, starting at 0; the source extension unless ``output_format`` overrides it."""
+        nth = Counter()
+        paths = []
+        for source in map(str, file_names):
+            stem, ext = os.path.splitext(source)
             if self.output_format is not None:
                 ext = "." + self.output_format
             if self.strategy == "all":
-                file_name_counts[file_name] += 1
-                name += f"_{file_name_counts[file_name]}"
-            path = os.path.join(output_dir, name + ext)
-            if self._writer is not None:        # process_dir: encode + write off the GPU worker's thread
-                self._writes.append(self._writer.submit(write_image, path, np.asarray(face)))
-            else:
-                write_image(path, np.asarray(face))
+                stem = f"{stem}_{nth[source]}"
+                nth[source] += 1
+            paths.append(os.path.join(output_dir, stem + ext))
+        return paths
+
+    def _emit(self, path: str, pixels: np.ndarray):
+        """Write one file: inline, or — inside process_dir — as a task on the I/O pool.  At most
+        MAX_PENDING_WRITES tasks are in flight: a slow disk stalls the GPU worker here instead of piling uint8
+        crops up in host memory, and a failed write surfaces at the next batch, not at the end of the run."""
+        if self._writer is None:
+            write_image(path, pixels)
+            return
+        self._write_slots.acquire()
+
+        def task():
+            try:
+                write_image(path, pixels)
+            finally:
+                self._write_slots.release()
+        with self._write_lock:
+            done = [w for w in self._writes if w.done()]
+            self._writes[:] = [w for w in self._writes if not w.done()]
+            self._writes.append(self._writer.submit(task))
+        for w in done:
+            w.result()               # re-raise an encode / write error of an earlier file now
+
+    def save_group(self, faces, file_names, output_dir: str):
+        """One directory of faces (or masks) — reference ``save_group``, cropper.py:554-609, with Pillow as the
+        encoder (arrays are RGB already, so there is no colour swap)."""
+        if len(faces) == 0:
+            return
+        os.makedirs(output_dir, exist_ok=True)
+        for path, pixels in zip(self._target_paths(file_names, output_dir), faces):
+            self._emit(path, np.asarray(pixels))
 
     def save_groups(self, faces, file_names, output_dir, attr_groups, mask_groups):
-        """cropper.py:611-746: attr x mask cross product of sub-directories."""
-        if attr_groups is None:
-            attr_groups = {"": list(range(len(faces)))}
-        if mask_groups is None:
-            mask_groups = {"": (list(range(len(faces))), None)}
-        for attr_name, attr_indices in attr_groups.items():
-            for mask_name, (mask_indices, masks) in mask_groups.items():
-                group_idx = list(set(attr_indices) & set(mask_indices))
-                group_dir = os.path.join(output_dir, attr_name, mask_name)
-                face_group = [faces[idx] for idx in group_idx]
-                file_name_group = file_names[group_idx]
-                self.save_group(face_group, file_name_group, group_dir)
-                if masks is not None:
-                    group_dir += "_mask"
-                    sel = masks[[list(mask_indices).index(i) for i in group_idx]]
-                    self.save_group(sel, file_name_group, group_dir)
+        """Directory tree ``output_dir/<attr group>/<mask group>[_mask]`` — reference ``save_groups``,
+        cropper.py:611-746.  A face lands in every (attr, mask) cell both groups list it in; the masks of a
+        cell go to the sibling ``<mask group>_mask`` directory under the same file names."""
+        everyone = list(range(len(faces)))
+        attrs = {"": everyone} if attr_groups is None else attr_groups
+        masks = {"": (everyone, None)} if mask_groups is None else mask_groups
+        for (attr_name, in_attr), (mask_name, (in_mask, mask_rows)) in itertools.product(attrs.items(), masks.items()):
+            # Order matters (it decides which face of a file gets which "_<k>"): the reference iterates the
+            # CPython set `set(a) & set(b)`, so the very same expression is evaluated here.
+            cell = list(set(in_attr) & set(in_mask))
+            cell_dir = os.path.join(output_dir, attr_name, mask_name)
+            sources = file_names[cell]
+            self.save_group([faces[i] for i in cell], sources, cell_dir)
+            if mask_rows is not None:
+                row_of = {}
+                for row, face in enumerate(in_mask):
+                    row_of.setdefault(face, row)
+                self.save_group(mask_rows[[row_of[i] for i in cell]], sources, cell_dir + "_mask")
 
     # ------------------------------------------------------------- processing
+    def _landmark_rows(self, table_names):
+        """file name -> rows of the user's landmark table, built once per table (not per batch)."""
+        cached = getattr(self, "_rows_cache", None)
+        if cached is None or cached[0] is not table_names:
+            rows_of = defaultdict(list)
+            for row, name in enumerate(table_names):
+                rows_of[str(name)].append(row)
+            cached = self._rows_cache = (table_names, rows_of)
+        return cached[1]
+
     @torch.no_grad()
     def process_batch(self, file_names, input_dir: str, output_dir: str):
         """cropper.py:748-850."""
@@ -213,19 +257,20 @@ class Cropper:
         paddings, landmarks, indices, images_dev = None, None, None, None
         with torch.cuda.device(self.device):
             if self.landmarks is None and self.det_model is None:
-                indices = list(range(len(file_names)))
+                indices = list(range(len(file_names)))              # one "face" per image, no alignment
             elif self.landmarks is not None:
-                indices, indices_ldm = [], []
-                for i, file_name in enumerate(file_names):
-                    indices_i = np.where(file_name == self.landmarks[1])[0]
-                    if len(indices_i) == 0:
-                        continue
-                    indices.extend([i] * len(indices_i))
-                    indices_ldm.extend(indices_i.tolist())
-                landmarks = self.landmarks[0][indices_ldm]
+                # user-supplied landmark sets (cropper.py:796-813): rows of the landmark table whose file name is in
+                # this batch, grouped by image in batch order; images without a row are dropped
+                table, table_names = self.landmarks
+                rows_of = self._landmark_rows(table_names)
+                pairs = [(i, row) for i, name in enumerate(file_names) for row in rows_of.get(str(name), ())]
+                indices = [i for i, _ in pairs]
+                landmarks = table[[row for _, row in pairs]]
             else:
-                images_dev, _, paddings = build_batch(images, self.resize_size, "constant", self.device)
-                lm_np, indices = self.det_model.predict(images_dev)
+                with trace.range("fcp:build_batch"):
+                    images_dev, _, paddings = build_batch(images, self.resize_size, "constant", self.device)
+                with trace.range("fcp:detect"):
+                    lm_np, indices = self.det_model.predict(images_dev)
                 landmarks = lm_np - paddings[indices][:, None, [2, 0]].astype(np.float32) if len(indices) else lm_np
 
             if landmarks is not None and len(landmarks) == 0:
@@ -235,32 +280,42 @@ class Cropper:
                 landmarks = np.stack([landmarks[:, s].mean(1) for s in slices], 1)
 
             if self.enh_model is not None:
-                if images_dev is not None:
-                    images_dev = self.enh_model.predict(images_dev, landmarks, indices)
-                else:
-                    images = [self.enh_model.predict(torch.from_numpy(im).to(self.device)[None], None, None)[0]
-                              .cpu().numpy() for im in images]
+                with trace.range("fcp:enhance"):
+                    if images_dev is not None:
+                        images_dev = self.enh_model.predict(images_dev, landmarks, indices)
+                    else:
+                        # ragged list (no detector): the reference hands the whole list to RRDBNet.predict
+                        # (cropper.py:833-836), whose gate measures every image's faces against the area of
+                        # images[0] (rrdb.py:124-140) and skips images that have no landmark set
+                        todo = self.enh_model.gate(len(images), images[0].shape[0], images[0].shape[1], landmarks, indices)
+                        for i in todo:
+                            images[i] = self.enh_model.predict(torch.from_numpy(images[i]).to(self.device)[None],
+                                                               None, None)[0].cpu().numpy()
 
             groups = (None, None)
             if landmarks is not None:
                 if images_dev is not None:
-                    crops_dev, ok = self._crop_align_device(
-                        images_dev, paddings, list(indices),
-                        torch.from_numpy(np.ascontiguousarray(landmarks, dtype=np.float32)).to(self.device))
+                    with trace.range("fcp:align"):
+                        crops_dev, ok = self._crop_align_device(
+                            images_dev, paddings, list(indices),
+                            torch.from_numpy(np.ascontiguousarray(landmarks, dtype=np.float32)).to(self.device))
                     keep = ok.cpu().numpy() != 0
                     crops_dev = crops_dev[torch.from_numpy(keep).to(self.device)]
                     indices = [i for i, k in zip(indices, keep) if k]
                     faces_dev, faces = crops_dev, crops_dev.cpu().numpy()
                 else:
-                    faces = self.crop_align(images, paddings, indices, landmarks)
+                    with trace.range("fcp:align"):
+                        faces = self.crop_align(images, paddings, indices, landmarks)
                     faces_dev = torch.from_numpy(faces).to(self.device) if len(faces) else None
             else:
                 faces, faces_dev = images, None
             if self.par_model is not None and len(faces) > 0:
                 if faces_dev is None:
                     faces_dev = [torch.from_numpy(np.ascontiguousarray(f)).to(self.device) for f in faces]
-                groups = self.par_model.predict(faces_dev)
-        self.save_groups(faces, file_names[indices], output_dir, *groups)
+                with trace.range("fcp:parse"):
+                    groups = self.par_model.predict(faces_dev)
+        with trace.range("fcp:save"):
+            self.save_groups(faces, file_names[indices], output_dir, *groups)
 
     def process_dir(self, input_dir: str, output_dir: str | None = None, desc: str | None = "Processing"):
         """cropper.py:852-909: batches of file names over a thread pool sharing the models."""
@@ -281,6 +336,7 @@ class Cropper:
         depth = max(2, 2 * self.num_processes)
         io = ThreadPoolExecutor(max_workers=self.io_threads, thread_name_prefix="fcp-io")
         self._writer, self._writes = io, []
+        self._write_slots = BoundedSemaphore(self.MAX_PENDING_WRITES)
         # every file is its own decode task (a batch decoded by one thread would cap the pipeline at `depth` decoders)
         def submit_read(i):
             return [io.submit(read_image, os.path.join(input_dir, f)) for f in file_batches[i]]
@@ -327,5 +383,5 @@ class Cropper:
             for w in self._writes:
                 w.result()                       # surface encode / write errors
         finally:
-            self._writer, self._writes = None, None
+            self._writer, self._writes, self._write_slots = None, None, None
             io.shutdown(wait=True)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 
 #define FCP_ERR_ARG (-1)
 #define FCP_ERR_HIP (-2)
@@ -38,3 +39,20 @@ void fcp_set_error(const char* fmt, ...);
   } while (0)
 
 static inline int fcp_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Per-device, thread-safe opt-in to more than 64 KiB of dynamic LDS.  hipFuncSetAttribute is per device, so a
+// process-wide "done" flag would leave a second GPU of the same process without the opt-in: `mask` (one static
+// atomic per kernel instantiation) holds one bit per device ordinal; concurrent first launches may both set
+// the attribute, which is idempotent.
+#define FCP_LDS_OPT_IN(kernel_ptr, bytes)                                                          \
+  do {                                                                                             \
+    static std::atomic<unsigned long long> _mask{0ull};                                            \
+    int _dev = 0;                                                                                  \
+    FCP_HIP_OK(hipGetDevice(&_dev));                                                               \
+    const unsigned long long _bit = 1ull << (_dev & 63);                                           \
+    if (!(_mask.load(std::memory_order_acquire) & _bit)) {                                         \
+      FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_ptr),                    \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));   \
+      _mask.fetch_or(_bit, std::memory_order_release);                                             \
+    }                                                                                              \
+  } while (0)

@@ -250,13 +250,8 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
 
 template <int BN, bool CIN4, bool BUF>
 int launch(const ConvK& k, hipStream_t s) {
-  static bool attr_set = false;
   const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
-  if (!attr_set) {
-    FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BN, CIN4, BUF>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  FCP_LDS_OPT_IN((&conv_igemm_f32<BN, CIN4, BUF>), lds);
   const int blocks = k.grid_m * k.grid_n;
   hipLaunchKernelGGL((conv_igemm_f32<BN, CIN4, BUF>), dim3(blocks), dim3(256), lds, s, k);
   FCP_LAUNCH_OK();
@@ -372,7 +367,8 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   // buffer-load path needs every operand addressable with 32-bit byte offsets
   const unsigned long in_bytes = (unsigned long)d->n * k.ph * k.pw * d->in_ld * 4ul;
   const unsigned long w_bytes = (unsigned long)(k.grid_n * d->tile_n) * k.wrow * 4ul;
-  const bool buf = in_bytes < 0xFFFFFFF0ul && w_bytes < 0xFFFFFFF0ul;
+  FCP_REQUIRE(!(d->flags & FCP_CONV_FLAT_ADDR) || d->precision == 0, "conv: FCP_CONV_FLAT_ADDR is a precision-0 (fp32 kernel) option");
+  const bool buf = in_bytes < 0xFFFFFFF0ul && w_bytes < 0xFFFFFFF0ul && !(d->flags & FCP_CONV_FLAT_ADDR);
   FCP_REQUIRE(d->precision == 0 || d->precision == 1, "conv: precision must be 0 (fp32) or 1 (fp16x3)");
   if (d->precision == 1) {
     FCP_REQUIRE(buf, "conv: the fp16x3 path needs tensors below 4 GiB (pack this layer with precision 0)");

@@ -308,13 +308,8 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
 
 template <int BN, bool CIN4, bool ASPLIT>
 int launch(const ConvK& k, hipStream_t s) {
-  static bool attr_set = false;
   const size_t lds = (size_t)2 * (BM + BN) * 128;
-  if (!attr_set) {
-    FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16x3<BN, CIN4, ASPLIT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  FCP_LDS_OPT_IN((&conv_igemm_f16x3<BN, CIN4, ASPLIT>), lds);
   hipLaunchKernelGGL((conv_igemm_f16x3<BN, CIN4, ASPLIT>), dim3(k.grid_m * k.grid_n), dim3(256), lds, s, k);
   FCP_LAUNCH_OK();
   return 0;

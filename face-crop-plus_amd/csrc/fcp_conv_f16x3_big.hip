@@ -435,13 +435,8 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
 
 template <int BN>
 int launch(ConvK k, hipStream_t s) {
-  static bool attr_set = false;
   const size_t lds = 2 * (size_t)STAGE;   // two stages; the epilogue's 256 x 128 fp32 tile aliases them
-  if (!attr_set) {
-    FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16x3_big<BN>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  FCP_LDS_OPT_IN((&conv_igemm_f16x3_big<BN>), lds);
   k.grid_m = fcp_cdiv(k.M, BMB);
   k.grid_n = fcp_cdiv(k.cout, BN);
   hipLaunchKernelGGL((conv_igemm_f16x3_big<BN>), dim3(k.grid_m * k.grid_n), dim3(NT), lds, s, k);

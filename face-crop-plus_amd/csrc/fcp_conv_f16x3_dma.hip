@@ -239,15 +239,10 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : 3)) conv_igemm_f16x3_dma
 
 template <int BN, int NST>
 int launch(const ConvK& k, hipStream_t s) {
-  static bool attr_set = false;
   size_t lds = (size_t)NST * (BM + BN) * 128;
   const size_t epi = (size_t)BM * BN * 4;       // epilogue C tile
   if (lds < epi) lds = epi;
-  if (!attr_set) {
-    FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16x3_dma<BN, NST>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  FCP_LDS_OPT_IN((&conv_igemm_f16x3_dma<BN, NST>), lds);
   hipLaunchKernelGGL((conv_igemm_f16x3_dma<BN, NST>), dim3(k.grid_m * k.grid_n), dim3(256), lds, s, k);
   FCP_LAUNCH_OK();
   return 0;

@@ -262,13 +262,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
 namespace fcp_conv {
 
 int launch_f16x3_halo(const ConvK& k, hipStream_t s) {
-  static bool attr_set = false;
   const size_t lds = 2 * (size_t)STAGE_B;
-  if (!attr_set) {
-    FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f16x3),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  FCP_LDS_OPT_IN(&conv3x3_halo_f16x3, lds);
   const long tiles = (long)k.n * ((k.out_h + TH - 1) / TH) * ((k.out_w + TW - 1) / TW);
   FCP_REQUIRE(tiles < (1L << 31), "conv(halo): too many tiles");
   hipLaunchKernelGGL(conv3x3_halo_f16x3, dim3((unsigned)tiles), dim3(256), lds, s, k);

@@ -255,13 +255,8 @@ extern "C" int fcp_stem7x7s2_relu_pool_u8(const uint8_t* images, int n, int h, i
   FCP_REQUIRE(np < (1L << 31) && (long)n * h * w * 3 < (1L << 40), "stem: batch too large");
   p.npatches = (int)np;
   for (int c = 0; c < 3; ++c) p.mean[c] = mean_rgb[c];
-  static bool attr_set = false;
   const size_t lds = (size_t)NSTEM * SPITCH * 4;       // stem staging (the binary16 image patch is a static array)
-  if (!attr_set) {
-    FCP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  FCP_LDS_OPT_IN(&stem_pool_kernel, lds);
   const int grid = (int)(np < 256 ? np : 256);
   hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, p);
   FCP_LAUNCH_OK();

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 7
+#define FCP_ABI_VERSION 8
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -106,7 +106,13 @@ typedef struct fcp_conv_desc {
    * bn3(conv3(o)) + bn_d(downsample(x)) runs as one convolution over [o | x(::s, ::s)] without ever
    * materialising the downsampled identity.  Needs kh = kw = 1, pad 0, precision 1, split32 `in`. */
   int32_t cin2, in2_ld, in2_h, in2_w, in2_stride;
+  /* FCP_CONV_FLAT_ADDR (precision 0 only): use 64-bit flat addressing even when every tensor is below
+   * 4 GiB.  The flat path is what tensors >= 4 GiB take on their own (RRDB's x4-resolution tail at 1024^2
+   * inputs); the flag exists so that it can be exercised — and tested — at small sizes. */
+  int32_t flags;
 } fcp_conv_desc;
+
+#define FCP_CONV_FLAT_ADDR 1
 
 int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);
 

@@ -390,3 +390,53 @@ def test_conv_randomized_shapes(device, precision):
             out = E.conv(pc, xa, act_slope=slope, alpha=alpha, res1=ra, res1_pre=pre, out_fmt=int(split_out), tile_m=tm, tile_n=tn)
             err = (out.nchw().cpu() - y).abs().max().item()
             assert err <= _tol(y) * (3 if not f16 else 1) + 1e-6, (it, k, stride, pad, cin, cout, n, h, w, tm, tn, err)
+
+
+@pytest.mark.parametrize("case", [
+    # n, h, w, cin, cout, k, stride, pad, tile_n, extras
+    (1, 20, 24, 64, 64, 3, 1, 1, 64, "lrelu"),        # HRconv's shape (rrdb.py:80)
+    (1, 20, 24, 64, 3, 3, 1, 1, 32, "slice3of4"),     # conv_last's shape: 3 channels into an NHWC4 buffer
+    (2, 13, 17, 128, 160, 1, 2, 0, 128, "res"),
+    (1, 37, 45, 3, 64, 7, 2, 3, 64, "cin4"),
+])
+def test_conv_flat_addressing(case, device):
+    """The 64-bit flat-addressing variant of the fp32 kernel (`launch<BN, *, false>`): on its own it only runs
+    for tensors >= 4 GiB (RRDB's x4 tail at 1024^2 inputs); FCP_CONV_FLAT_ADDR forces it at test sizes.  Must
+    equal the buffer-addressed variant bit for bit and the torch fp32 reference to roundoff."""
+    from face_crop_plus_amd import engine as E
+    n, h, w, cin, cout, k, stride, pad, tile_n, extra = case
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, stride, pad)
+    pc = E.pack_conv(wt, b, None, stride, pad, device, precision="f32")
+    if extra == "cin4":
+        xin = E.Act(_nhwc(F.pad(x, (0, 0, 0, 0, 0, 1)), device))
+    else:
+        xin = E.Act(_nhwc(x, device))
+    kw = {}
+    if extra == "lrelu":
+        kw["act_slope"], ref = 0.2, F.leaky_relu(ref, 0.2)
+    if extra == "res":
+        r = torch.randn(ref.shape, generator=g)
+        kw.update(res1=E.Act(_nhwc(r, device)), res1_pre=True, act_slope=0.0)
+        ref = F.relu(ref + r)
+    outs = []
+    for flat in (False, True):
+        if extra == "slice3of4":
+            buf = E.Act(torch.zeros(n, ref.shape[2], ref.shape[3], 4, device=device))
+            outs.append(E.conv(pc, xin, buf.slice(0, 3), tile_n=tile_n, flat=flat, **kw).nchw().cpu())
+            assert float(buf.buf[..., 3].abs().max()) == 0.0, "the pad channel of the NHWC4 buffer was written"
+        else:
+            outs.append(E.conv(pc, xin, tile_n=tile_n, flat=flat, **kw).nchw().cpu())
+    assert torch.equal(outs[0], outs[1]), "flat and buffer addressing disagree"
+    assert (outs[1] - ref).abs().max().item() <= _tol(ref)
+
+
+def test_conv_flat_flag_rejected_on_f16x3(device):
+    from face_crop_plus_amd import engine as E
+    wt = torch.randn(64, 64, 1, 1)
+    pc = E.pack_conv(wt, None, None, 1, 0, device, precision="f16x3")
+    with pytest.raises(RuntimeError, match="FCP_CONV_FLAT_ADDR"):
+        E.conv(pc, E.Act(torch.zeros(1, 4, 4, 64, device=device)), flat=True)

@@ -180,3 +180,91 @@ def test_crop_align_plumbing_like_reference(device):
     assert c.crop_align(images, paddings, [], lms[:0]).shape == (0,)
     lms[1] = 7.0                                                    # all five points coincide: no transform -> face dropped
     assert c.crop_align(images, paddings, [0, 1, 1], lms[:3]).shape == (2, 112, 96, 3)
+
+
+# (width, height) of the reference's eight demo/input_images
+DEMO_GEOMETRIES = [(1024, 624), (409, 687), (423, 594), (500, 281), (1648, 2464), (610, 826), (410, 594), (334, 500)]
+
+
+def test_c1_demo_geometries_default_config(tmp_path, device):
+    """BASELINE configs[0] shape: Cropper(strategy='largest', det_threshold=0.6) with every other argument at its
+    default (resize_size 1024, output_size 256, batch_size 8) on eight images with the demo set's geometries
+    (up- and down-scaled, portrait and landscape, INTER_CUBIC and INTER_AREA legs of as_batch), against the oracle
+    chain batch_ref -> retinaface_ref -> align_ref.  The real photos / pretrained weights are not available
+    here, so the pixels are generated and the weights are the seeded generator's.
+
+    Tight form of the end-to-end check: the batch is byte-exact, faces / order identical, landmarks within
+    1e-3 px of the oracle's, and the written crops are BYTE-EXACT to the oracle's estimate + warp applied to
+    the landmarks the GPU produced (the 1e-4 px landmark noise is the only thing that could flip a byte)."""
+    from PIL import Image
+    from face_crop_plus_amd import Cropper, weights, utils
+    from face_crop_plus_amd.batch import build_batch
+    src = tmp_path / "demo"
+    src.mkdir()
+    rng = np.random.default_rng(2024)
+    for i, (w, h) in enumerate(DEMO_GEOMETRIES):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        im = np.stack([128 + 100 * np.sin(xx / (11 + 3 * c)) * np.cos(yy / (7 + 5 * c)) for c in range(3)], -1)
+        im = np.clip(im + rng.normal(0, 25, im.shape), 0, 255).astype(np.uint8)
+        Image.fromarray(im).save(src / f"demo{i}.png")
+    sd = weights.generate_state_dict("retinaface")
+    c = Cropper(strategy="largest", det_threshold=0.6, device="cuda:0", weights={"retinaface": sd})
+    assert (c.output_size, c.resize_size, c.batch_size, c.face_factor) == ((256, 256), (1024, 1024), 8, 0.65)
+    out = tmp_path / "out"
+    c.process_dir(str(src), str(out), desc=None)
+    names = sorted(os.listdir(src))
+    imgs, _ = utils.read_images(names, str(src))
+    batch, _, pads = B.as_batch(imgs, (1024, 1024))
+    dev_batch, _, dpads = build_batch(imgs, c.resize_size, "constant", c.device)
+    assert dpads.tolist() == pads.tolist() and np.array_equal(dev_batch.cpu().numpy(), batch)
+    lm_ref, idx_ref = R.predict(torch.from_numpy(batch).permute(0, 3, 1, 2).float(), sd, "largest", 0.6)
+    lm, idx = c.det_model.predict(dev_batch)
+    assert list(idx) == list(idx_ref) and len(idx) >= 6
+    err = float(np.abs(lm - lm_ref).max())
+    print("C1 landmark error vs oracle:", err)
+    assert err < 1e-3
+    assert sorted(os.listdir(out)) == [names[i] for i in idx]
+    un = lm - pads[idx][:, None, [2, 0]].astype(np.float32)
+    crops = A.crop_align(batch, pads, list(idx), un, A.landmarks_target((256, 256), 0.65), (256, 256), "constant")
+    for k, i in enumerate(idx):
+        got = np.asarray(Image.open(out / names[i]).convert("RGB"))
+        assert np.array_equal(got, crops[k]), f"{names[i]}: crop differs from oracle(estimate + warp) of the same landmarks"
+
+
+def test_two_croppers_two_threads_one_device(tmp_path, device):
+    """Native state is per device and thread safe: two Croppers built and run concurrently from two host threads
+    on cuda:0 (own HIP stream each; shared autotune cache and per-kernel LDS opt-in) write exactly what one
+    Cropper writes alone."""
+    import threading
+    from PIL import Image
+    from face_crop_plus_amd import Cropper
+    from face_crop_plus_amd import engine as E
+    src = tmp_path / "src"
+    src.mkdir()
+    rng = np.random.default_rng(13)
+    for i in range(8):
+        Image.fromarray(rng.integers(0, 256, (150, 170, 3), dtype=np.uint8)).save(src / f"t{i}.png")
+    kw = dict(output_size=64, resize_size=(192, 160), strategy="all", det_threshold=0.55, batch_size=4,
+              device="cuda:0", weights={"retinaface": "generated"})
+    E.Autotune.cache.clear()                       # both threads meet untuned shapes
+    errors, outs = [], {}
+
+    def run(tag):
+        try:
+            with torch.cuda.device(0), torch.cuda.stream(torch.cuda.Stream()):
+                c = Cropper(**kw)
+                c.process_dir(str(src), str(tmp_path / tag), desc=None)
+                torch.cuda.current_stream().synchronize()
+            outs[tag] = {f: (tmp_path / tag / f).read_bytes() for f in sorted(os.listdir(tmp_path / tag))}
+        except Exception as e:                      # surfaced below: a thread's exception is otherwise lost
+            errors.append((tag, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in ("a", "b")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    run("solo")
+    assert not errors, errors
+    assert len(outs["solo"]) > 8 and outs["a"] == outs["b"] == outs["solo"]
