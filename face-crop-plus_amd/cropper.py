@@ -53,8 +53,8 @@ class Cropper:
     ):
         """Arguments as in the reference (cropper.py:139-156).  ``device`` must be a GPU
         (``"cuda:N"``); ``weights`` optionally maps "retinaface"/"rrdb"/"bisenet" to a
-        state dict / path / "generated" (default: real checkpoints when present in
-        ``$FCP_WEIGHTS_DIR`` or the torch hub cache, else the seeded generator)."""
+        state dict / path / "generated" (default: the real checkpoints, from ``$FCP_WEIGHTS_DIR`` or the
+        torch hub cache, else downloaded like the reference does; there is no silent random-weight fallback)."""
         self.output_size = output_size
         self.output_format = output_format
         self.resize_size = resize_size

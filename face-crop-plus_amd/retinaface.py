@@ -41,8 +41,8 @@ class RetinaFace:
     # ------------------------------------------------------------------ load
     def load(self, device: str | torch.device = "cuda:0", weights=None, precision=None):
         """Pack the state dict for the HIP engine (reference ``LoadMixin.load``,
-        _layers.py:16-25).  ``weights``: None (real checkpoint if present, else the
-        deterministic generator), a path, a state dict, or "generated".  ``precision``:
+        _layers.py:16-25).  ``weights``: None (the real checkpoint: local file, else the
+        reference's download, else an error), a path, a state dict, or "generated" (seeded random weights).  ``precision``:
         "f16x3" (split-fp16 MFMA, fp32-equivalent accuracy, default) or "f32" (exact fp32 MFMA)."""
         device = torch.device(device)
         if device.type != "cuda":

@@ -59,10 +59,13 @@ def get_ldm_slices(num_tgt_landmarks: int, num_src_landmarks: int):
 
 
 def read_image(path: str):
-    """One file -> RGB uint8 HWC array, or None (with the reference's warning) when it cannot be read."""
-    from PIL import Image
+    """One file -> RGB uint8 HWC array, or None (with the reference's warning) when it cannot be read.
+    Like ``cv2.imread`` (utils.py:262), the EXIF orientation tag is applied: phone photos arrive upright, and
+    user-supplied landmark files — which live in that oriented frame — point at the right pixels."""
+    from PIL import Image, ImageOps
     try:
         with Image.open(path) as im:
+            im = ImageOps.exif_transpose(im)
             return np.asarray(im.convert("RGB"), dtype=np.uint8)
     except Exception:
         warnings.warn(f"Could not read the image {path}")
@@ -146,7 +149,29 @@ def clean_names(input_dir: str, output_dir: str | None = None, max_chars: int = 
             os.rename(os.path.join(input_dir, original), os.path.join(input_dir, stem + ext))
 
 
-def write_image(path: str, image: np.ndarray):
-    """RGB (or single-channel mask) uint8 array -> file; format from the extension."""
+# Encoder settings of ``cv2.imwrite`` with no parameters (cropper.py:605-609), so that files written here have the
+# fidelity and roughly the size of the reference's: JPEG quality 95 with 4:2:0 chroma subsampling (Pillow's own
+# default, quality 75, is visibly lossier), PNG at zlib level 1 (lossless either way: only size / speed differ),
+# WebP lossless (OpenCV's default quality setting means lossless).
+_ENCODER_KW = {
+    ".jpg": dict(format="JPEG", quality=95, subsampling="4:2:0"),
+    ".jpeg": dict(format="JPEG", quality=95, subsampling="4:2:0"),
+    ".jpe": dict(format="JPEG", quality=95, subsampling="4:2:0"),
+    ".png": dict(format="PNG", compress_level=1),
+    ".webp": dict(format="WEBP", lossless=True),
+    ".bmp": dict(format="BMP"),
+    ".tif": dict(format="TIFF"),
+    ".tiff": dict(format="TIFF"),
+}
+
+
+def write_image(path: str, image: np.ndarray) -> bool:
+    """RGB (or single-channel mask) uint8 array -> file; format from the extension, ``cv2.imwrite`` defaults.
+    An extension with no encoder warns and returns False (the file is skipped) instead of raising."""
     from PIL import Image
-    Image.fromarray(image).save(path)
+    kw = _ENCODER_KW.get(os.path.splitext(path)[1].lower())
+    if kw is None:
+        warnings.warn(f"Could not write the image {path}: no encoder for this extension")
+        return False
+    Image.fromarray(image).save(path, **kw)
+    return True

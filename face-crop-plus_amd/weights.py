@@ -194,34 +194,81 @@ def generate_state_dict(model: str, seed: int = 0, as_torch: bool = True):
     return out
 
 
-def find_checkpoint(model: str):
-    """Locate a user-supplied real checkpoint (never downloads; reference
-    ``LoadMixin.get_weights`` uses torch.hub, _layers.py:27-35)."""
-    fn = WEIGHTS_FILENAMES[model]
-    cands = []
+URL_ROOT = "https://github.com/mantasu/face-crop-plus/releases/download/v1.0.0/"   # reference _layers.py:13
+
+
+def checkpoint_dirs():
+    """Where a real checkpoint is looked for, in order: $FCP_WEIGHTS_DIR, then torch.hub's checkpoint cache
+    (``torch.hub.get_dir()`` honours $TORCH_HOME / $XDG_CACHE_HOME) — the directory the reference's
+    ``torch.hub.load_state_dict_from_url`` (_layers.py:27-35) downloads into."""
+    dirs = []
     if os.environ.get("FCP_WEIGHTS_DIR"):
-        cands.append(os.path.join(os.environ["FCP_WEIGHTS_DIR"], fn))
-    cands.append(os.path.join(os.path.expanduser("~/.cache/torch/hub/checkpoints"), fn))
-    for c in cands:
+        dirs.append(os.environ["FCP_WEIGHTS_DIR"])
+    try:
+        import torch
+        dirs.append(os.path.join(torch.hub.get_dir(), "checkpoints"))
+    except Exception:
+        dirs.append(os.path.join(os.path.expanduser("~/.cache/torch/hub"), "checkpoints"))
+    return dirs
+
+
+def find_checkpoint(model: str):
+    """Locate a real checkpoint on disk (no network access)."""
+    fn = WEIGHTS_FILENAMES[model]
+    for d in checkpoint_dirs():
+        c = os.path.join(d, fn)
         if os.path.isfile(c):
             return c
     return None
 
 
+def _fetch_checkpoint(model: str):
+    """What the reference does when the file is not cached: download it from the release page
+    (_layers.py:33-35).  Skipped with FCP_OFFLINE=1; any failure is reported by the caller."""
+    import torch
+    return torch.hub.load_state_dict_from_url(URL_ROOT + WEIGHTS_FILENAMES[model], map_location="cpu", progress=False)
+
+
 def load_state_dict(model: str, source=None, seed: int = 0):
-    """``source``: None (checkpoint if found, else generated), a path, a dict, or
-    the string ``"generated"``."""
+    """``source``: a state dict, a ``.pth`` path, the string ``"generated"`` (the seeded random-init generator:
+    an explicit opt-in for tests / benchmarks — its detections are meaningless), or None.
+
+    None means "the real weights", as in the reference: a checkpoint found in ``checkpoint_dirs()``, else the
+    reference's download; when neither works this raises — it never silently falls back to random weights.
+    ``FCP_WEIGHTS=generated`` in the environment turns None into "generated" (with a warning), for smoke runs of
+    the CLI on boxes without the checkpoints."""
     import torch
     if isinstance(source, dict):
         sd = source
     elif source == "generated":
         sd = generate_state_dict(model, seed)
+    elif isinstance(source, str):
+        sd = torch.load(source, map_location="cpu")
     else:
-        path = source if isinstance(source, str) else find_checkpoint(model)
-        if path is None:
+        path = find_checkpoint(model)
+        if path is not None:
+            sd = torch.load(path, map_location="cpu")
+        elif os.environ.get("FCP_WEIGHTS") == "generated":
+            import warnings
+            warnings.warn(f"{model}: FCP_WEIGHTS=generated — using seeded RANDOM weights; detections, crops and "
+                          f"masks are meaningless (plumbing / benchmark use only)")
             sd = generate_state_dict(model, seed)
         else:
-            sd = torch.load(path, map_location="cpu")
+            err = "FCP_OFFLINE=1"
+            if os.environ.get("FCP_OFFLINE") != "1":
+                try:
+                    return _validated(model, _fetch_checkpoint(model))
+                except Exception as e:               # no network, HTTP error, disk full, ...
+                    err = f"{type(e).__name__}: {e}"
+            raise FileNotFoundError(
+                f"{model}: checkpoint {WEIGHTS_FILENAMES[model]} not found in {checkpoint_dirs()} and the download "
+                f"from {URL_ROOT} failed ({err}).  Put the file into $FCP_WEIGHTS_DIR or the torch hub cache, pass "
+                f"weights={{'{model}': <path | state dict>}}, or opt in to random weights explicitly with "
+                f"weights={{'{model}': 'generated'}} / FCP_WEIGHTS=generated.")
+    return _validated(model, sd)
+
+
+def _validated(model: str, sd):
     want = {n: tuple(s) for n, s, _ in SPECS[model]()}
     for k, shp in want.items():
         if k not in sd:

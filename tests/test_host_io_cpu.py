@@ -1,0 +1,140 @@
+"""Host I/O and weight-loading policy (CPU only)."""
+import io
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+
+def _smooth(h=96, w=128):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    return np.stack([127 + 100 * np.sin(xx / 9 + c) * np.cos(yy / 7) for c in range(3)], -1).clip(0, 255).astype(np.uint8)
+
+
+def test_jpeg_written_at_opencv_default_quality(tmp_path):
+    """cv2.imwrite's default is quality 95 / 4:2:0 (the reference writer, cropper.py:605-609); Pillow's own default
+    (75) would give visibly lossier, much smaller files."""
+    from PIL import Image
+    from face_crop_plus_amd.utils import write_image
+    img = _smooth()
+    assert write_image(str(tmp_path / "a.jpg"), img) is True
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, format="JPEG")                 # Pillow default, for comparison
+    size95, size75 = (tmp_path / "a.jpg").stat().st_size, len(buf.getvalue())
+    assert size95 > 1.3 * size75
+    with Image.open(tmp_path / "a.jpg") as im:
+        assert im.get_format_mimetype() == "image/jpeg"
+        q = im.quantization[0]
+        back = np.asarray(im.convert("RGB")).astype(np.float64)
+    assert max(q) <= 12, "luma quantisation table is coarser than quality 95"      # q95 table: entries 1..10
+    psnr = 10 * np.log10(255 ** 2 / np.mean((back - img) ** 2))
+    psnr75 = 10 * np.log10(255 ** 2 / np.mean((np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB")).astype(np.float64) - img) ** 2))
+    assert psnr > 38 and psnr > psnr75 + 3, (psnr, psnr75)
+
+
+def test_png_webp_lossless_and_unknown_extension(tmp_path):
+    from PIL import Image
+    from face_crop_plus_amd.utils import write_image
+    img = _smooth()
+    mask = (img[..., 0] > 127).astype(np.uint8) * 255
+    for name, arr in (("a.png", img), ("m.png", mask), ("a.webp", img), ("a.bmp", img)):
+        assert write_image(str(tmp_path / name), arr)
+        back = np.asarray(Image.open(tmp_path / name))
+        assert np.array_equal(back, arr), name
+    with pytest.warns(UserWarning, match="no encoder"):
+        assert write_image(str(tmp_path / "a.xyz"), img) is False
+    assert not (tmp_path / "a.xyz").exists()
+
+
+def test_read_image_applies_exif_orientation(tmp_path):
+    """cv2.imread (utils.py:262) honours the EXIF orientation tag; so must the Pillow reader."""
+    from PIL import Image
+    from face_crop_plus_amd.utils import read_image
+    img = _smooth(60, 90)
+    im = Image.fromarray(img)
+    exif = im.getexif()
+    exif[0x0112] = 6                                  # "rotate 90 CW to display"
+    im.save(tmp_path / "rot.png", exif=exif)          # PNG keeps the pixels exact
+    got = read_image(str(tmp_path / "rot.png"))
+    assert got.shape == (90, 60, 3)
+    assert np.array_equal(got, np.rot90(img, k=-1))
+    im.save(tmp_path / "plain.png")
+    assert np.array_equal(read_image(str(tmp_path / "plain.png")), img)
+    (tmp_path / "bad.png").write_bytes(b"nope")
+    with pytest.warns(UserWarning, match="Could not read"):
+        assert read_image(str(tmp_path / "bad.png")) is None
+
+
+def test_weights_never_fall_back_silently(tmp_path, monkeypatch):
+    """No checkpoint + no download => an error naming the places searched; random weights only on explicit opt-in."""
+    import torch
+    from face_crop_plus_amd import weights as W
+    monkeypatch.setenv("FCP_WEIGHTS_DIR", str(tmp_path / "w"))
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "th"))
+    monkeypatch.setenv("FCP_OFFLINE", "1")
+    monkeypatch.delenv("FCP_WEIGHTS", raising=False)
+    assert W.checkpoint_dirs() == [str(tmp_path / "w"), str(tmp_path / "th" / "hub" / "checkpoints")]
+    with pytest.raises(FileNotFoundError, match="bise_parser.pth"):
+        W.load_state_dict("bisenet")
+    assert W.load_state_dict("bisenet", "generated")["conv_out.conv_out.weight"].shape == (19, 256, 1, 1)
+    monkeypatch.setenv("FCP_WEIGHTS", "generated")
+    with pytest.warns(UserWarning, match="RANDOM weights"):
+        W.load_state_dict("bisenet")
+    monkeypatch.delenv("FCP_WEIGHTS")
+    # a real file in the torch hub cache (where the reference's download lands) is picked up
+    os.makedirs(tmp_path / "th" / "hub" / "checkpoints")
+    sd = W.generate_state_dict("bisenet", seed=3)
+    torch.save(sd, tmp_path / "th" / "hub" / "checkpoints" / "bise_parser.pth")
+    got = W.load_state_dict("bisenet")
+    assert torch.equal(got["ffm.conv1.weight"], sd["ffm.conv1.weight"])
+    # download path: a failing fetch is reported, a working one is validated and used
+    os.remove(tmp_path / "th" / "hub" / "checkpoints" / "bise_parser.pth")
+    monkeypatch.delenv("FCP_OFFLINE")
+    monkeypatch.setattr(W, "_fetch_checkpoint", lambda m: (_ for _ in ()).throw(OSError("no route")))
+    with pytest.raises(FileNotFoundError, match="no route"):
+        W.load_state_dict("bisenet")
+    monkeypatch.setattr(W, "_fetch_checkpoint", lambda m: sd)
+    assert torch.equal(W.load_state_dict("bisenet")["ffm.conv2.weight"], sd["ffm.conv2.weight"])
+
+
+def test_bounded_async_writes(tmp_path, monkeypatch):
+    """process_dir's writer: at most MAX_PENDING_WRITES tasks in flight, errors surface at a later emit."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    import face_crop_plus_amd.cropper as CR
+    gate, inflight, peak = threading.Event(), [0], [0]
+    lock = threading.Lock()
+
+    def slow_write(path, img):
+        with lock:
+            inflight[0] += 1
+            peak[0] = max(peak[0], inflight[0])
+        gate.wait(5)
+        with lock:
+            inflight[0] -= 1
+        if path.endswith("boom.png"):
+            raise OSError("disk full")
+    monkeypatch.setattr(CR, "write_image", slow_write)
+    c = CR.Cropper.__new__(CR.Cropper)
+    c.MAX_PENDING_WRITES = 3
+    c._writer, c._writes = ThreadPoolExecutor(8), []
+    c._write_slots, c._write_lock = threading.BoundedSemaphore(3), threading.Lock()
+    c.strategy, c.output_format = "largest", None
+    t = threading.Thread(target=lambda: c.save_group([np.zeros((2, 2, 3), np.uint8)] * 6,
+                                                     np.array([f"f{i}.png" for i in range(6)]), str(tmp_path)))
+    t.start()
+    t.join(0.5)
+    assert t.is_alive() and peak[0] == 3          # the producer is blocked on the 4th write
+    gate.set()
+    t.join(5)
+    assert not t.is_alive() and peak[0] == 3
+    c._emit(str(tmp_path / "boom.png"), np.zeros((2, 2, 3), np.uint8))
+    for w in list(c._writes):
+        try:
+            w.result()
+        except OSError:
+            pass
+    with pytest.raises(OSError, match="disk full"):
+        c._emit(str(tmp_path / "next.png"), np.zeros((2, 2, 3), np.uint8))
+    c._writer.shutdown(wait=True)
