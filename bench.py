@@ -5,19 +5,29 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one synthetic batch that is already
-resident in HBM: uint8 NHWC images -> RetinaFace (fp32 MFMA convs) -> decode /
-NMS / strategy -> 5-point similarity -> warpAffine crops (uint8, on device).
+resident in HBM: uint8 NHWC images -> RetinaFace (MFMA convs) -> decode / NMS /
+strategy -> 5-point similarity -> warpAffine crops (uint8, on device).
 Workload at N=1 is BASELINE.json configs[1]: batch 64, 640x640, strategy
 "largest", det_threshold 0.6, output 256x256.  Multi-GPU: every rank owns an
 independent batch (weak scaling, no data-path collective); weights are
 broadcast once from rank 0 over RCCL.
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (conv
-engine, fp32 MFMA peak) and `cpu_baseline` (the oracle timed on the host cores).
+engine), `cpu_baseline` (the oracle timed on the host cores) and — at N=1 —
+`extra`: the other BASELINE configurations / modes measured in the same run
+(configs[2] with and without RRDB enhancement, the exact-fp32 mode), each with
+its own ms_per_step, steps and roofline sub-record.
+
+The detector is run the way the product runs it (`RetinaFace.streams` = 2: the
+two halves of the batch on two HIP streams).  Per-launch conv durations for the
+roofline are taken with HIP events in separate single-stream passes right after
+the timed region: launches that share the device would inflate each other's
+durations (`--streams 1` times them inside the timed region instead).
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -51,22 +61,199 @@ def parse():
     ap.add_argument("--strategy", default="largest")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` workloads (configs[2], fp32 mode)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
                     help="conv arithmetic: split-fp16 MFMA (fp32-equivalent accuracy) or exact fp32 MFMA")
     ap.add_argument("--graph", action="store_true",
                     help="replay the detection step from a captured HIP graph (small, launch-bound batches)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path")
-    ap.add_argument("--free-running", action="store_true",
-                    help="with --streams S: do not re-join the streams after every step (S independent workers)")
-    ap.add_argument("--no-live-roofline", action="store_true",
-                    help="time the conv launches in one extra step after the timed region instead of inside it")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the batch is split over (2: the two half-batches overlap on the device like "
-                         "process_dir's GPU workers, +4..6 %% over 1; the default stays 1 so that per-launch durations "
-                         "- HIP events here, rocprofv3 in profiles/ - are those of kernels that own the device)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the detector splits a batch over (product default 2; 1 = single stream, conv "
+                         "launches then timed inside the timed region)")
+    ap.add_argument("--roofline-steps", type=int, default=3, help="single-stream passes the conv launches are timed in")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
+
+
+class Pipeline:
+    """One configuration of the hot path on one GPU: models + a resident synthetic batch + step()."""
+
+    def __init__(self, dev, sd_det, *, full, batch, size, out_size, strategy, precision, enhance, streams, seed,
+                 graph=False, sd_enh=None, sd_par=None):
+        from face_crop_plus_amd import align
+        from face_crop_plus_amd.cropper import landmarks_target
+        from face_crop_plus_amd.retinaface import RetinaFace
+        self.dev, self.full, self.batch, self.size, self.out_size = dev, full, batch, size, out_size
+        self.strategy, self.precision, self.enhance = strategy, precision, enhance
+        self.align = align
+        self.det = RetinaFace(strategy, 0.6).load(dev, sd_det, precision)
+        self.det.streams = streams
+        self.tgt = torch.from_numpy(landmarks_target((out_size, out_size), 0.65)).to(dev)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.images = torch.randint(0, 256, (batch, size, size, 3), generator=g, dtype=torch.uint8).to(dev)
+        self.face_total = torch.zeros((), dtype=torch.int64, device=dev)
+        self.enhanced_total = 0
+        self.enh = self.par = None
+        if full:
+            from face_crop_plus_amd.rrdb import RRDBNet
+            from face_crop_plus_amd.bise import BiSeNet
+            if enhance != "none":
+                self.enh = RRDBNet(0.001).load(dev, sd_enh, precision)
+            self.par = BiSeNet({"glasses": [6]}, {"eyes": [4, 5]}, 32).load(dev, sd_par, precision)
+        self.graphed = self.det.graphed(batch, size, size) if graph else None
+
+    def step(self, count=True):
+        from face_crop_plus_amd import trace
+        imgs = self.images
+        with trace.range("fcp:detect"):
+            if self.graphed is not None:
+                self.graphed[0].copy_(imgs)
+                self.graphed[2].replay()
+                res = self.graphed[1]
+            else:
+                res = self.det.detect(imgs, max_faces=imgs.shape[0] if self.strategy != "all" else None)
+        if self.enh is not None:
+            with trace.range("fcp:enhance"):
+                imgs = imgs.clone()                      # enhancement rewrites the batch in place
+                which = list(range(imgs.shape[0]))
+                if self.enhance == "rule":               # rrdb.py:124-140 needs the landmarks on the host
+                    nf_h = int(res["face_offset"][-1].item())
+                    which = self.enh.gate(imgs.shape[0], imgs.shape[1], imgs.shape[2],
+                                          res["landmarks"][:nf_h].cpu().numpy(), res["img_idx"][:nf_h].cpu().tolist())
+                self.enhanced_total += len(which)
+                self.enh.enhance_u8(imgs, which)
+        with trace.range("fcp:align"):
+            crops, ok, _ = self.align.crop_align(imgs, res["img_idx"], res["landmarks"], self.tgt,
+                                                 (self.out_size, self.out_size), 0)
+        if self.par is not None:
+            with trace.range("fcp:parse"):
+                self.par.parse(crops)                    # label maps + class histograms stay on the device
+        if count:
+            nf = torch.clamp(res["face_offset"][-1].to(torch.int64), max=res["max_faces"])
+            valid = (torch.arange(res["max_faces"], device=self.dev) < nf) & (ok != 0)
+            self.face_total.add_(valid.sum())
+        return crops
+
+    def describe(self):
+        head = (f"full pipeline (detect + RRDB enhance[{self.enhance}] + align + BiSeNet parse)" if self.full
+                else "RetinaFace detect + 5-pt align/crop")
+        s = (f"{head}, batch={self.batch}/GPU synthetic {self.size}x{self.size} RGB, strategy={self.strategy}, "
+             f"det_threshold=0.6, output {self.out_size}x{self.out_size}")
+        if self.det.streams > 1:
+            s += f", detector on {self.det.streams} HIP streams x {self.batch // self.det.streams} images"
+        return s
+
+
+def time_pipeline(p: Pipeline, steps, warmup, autotune=True, dist=None, live_events=False):
+    """Initialisation pass (lazy loads, tile tuning), `warmup` untimed steps, then exactly `steps` timed steps
+    bracketed by barrier + synchronize.  Returns (elapsed seconds, faces counted in the timed steps)."""
+    from face_crop_plus_amd import engine as E
+    E.Autotune.enabled = autotune
+    p.step(True)
+    torch.cuda.synchronize()
+    E.Autotune.enabled = False
+    for _ in range(warmup):
+        p.step(True)
+    torch.cuda.synchronize()
+    p.face_total.zero_()
+    p.enhanced_total = 0
+    if live_events:
+        E.ConvStats.timing = []
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        p.step(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, p.face_total.clone()
+
+
+def conv_roofline(p: Pipeline, nsteps, live):
+    """Roofline record of the conv engine from per-launch HIP events on the launch stream: the events of the timed
+    steps (`live`, single-stream runs) or of `nsteps` extra single-stream passes right after the timed region."""
+    from face_crop_plus_amd import engine as E
+    if not live:
+        saved, p.det.streams = p.det.streams, 1
+        graphed, p.graphed = p.graphed, None          # per-launch events need the eager launches
+        p.step(False)                                  # shapes first seen on one stream (untimed)
+        torch.cuda.synchronize()
+        E.ConvStats.timing = []
+        for _ in range(nsteps):
+            p.step(False)
+        torch.cuda.synchronize()
+        p.det.streams, p.graphed = saved, graphed
+    timing, E.ConvStats.timing = E.ConvStats.timing, None
+    conv_ms = sum(a.elapsed_time(b) for a, b, _ in timing) / nsteps
+    conv_flops = sum(f for _, _, f in timing) / nsteps
+    launches = len(timing) // nsteps
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+    split = p.precision == "f16x3"
+    peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+    traffic, traffic_src = None, None
+    pdir = os.path.join(ROOT, "profiles")
+    prof = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_conv.json")) if os.path.isdir(pdir) else []
+    prof = [f for f in prof if ("f16x3" in f) == split]
+    if prof and not p.full and p.batch == 64 and p.size == 640:
+        with open(os.path.join(pdir, prof[-1])) as f:
+            traffic = round(json.load(f)["hbm_bytes_per_launch"])
+        traffic_src = "profiles/" + prof[-1]
+    return {"bound": "mfma",
+            "kernel": ("conv_igemm_f16x3 family (3x v_mfma_f32_32x32x16_f16 per product: x = hi + lo split)" if split
+                       else "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)"),
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            # the split path executes 3 matrix FLOP per algorithmic FLOP: utilisation of the f16 pipe
+            "executed_frac": round(achieved * (3 if split else 1) / peak, 4),
+            "traffic": traffic,
+            "traffic_unit": "HBM bytes per conv launch (PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+            "traffic_source": traffic_src,
+            # PMC counters cannot be read from inside the process: `traffic` is the committed rocprofv3 --pmc
+            # measurement of this same command, not a value measured in this run
+            "traffic_static": traffic is not None,
+            "measured": ("HIP events around every conv launch of the timed steps" if live else
+                         f"HIP events around every conv launch of {nsteps} single-stream passes over the batch right "
+                         f"after the timed region"),
+            "launches_per_step": launches, "algorithmic_gflop_per_step": round(conv_flops / 1e9, 2),
+            "avg_launch_ms": round(conv_ms / launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
+
+
+def run_extra(dev, sds, args):
+    """The other configurations, one GPU, measured like the headline (same Pipeline / timing / roofline code)."""
+    out = {}
+
+    def one(key, note, steps, warmup, **kw):
+        try:
+            p = Pipeline(dev, sds["retinaface"], out_size=args.out_size, strategy=args.strategy, streams=args.streams,
+                         seed=4321, sd_enh=sds.get("rrdb"), sd_par=sds.get("bisenet"), **kw)
+            elapsed, faces = time_pipeline(p, steps, warmup, autotune=not args.no_autotune)
+            rec = {"workload": p.describe(), "note": note, "value": round(int(faces.item()) / elapsed, 2),
+                   "unit": "faces/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+                   "dtype": p.precision}
+            if p.enh is not None:
+                rec["images_enhanced_per_step"] = p.enhanced_total / steps
+            rec["roofline"] = conv_roofline(p, 1 if p.enh is not None else 2, live=False)
+            out[key] = rec
+            del p
+        except Exception as e:                           # an extra must never take the headline line down
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    from face_crop_plus_amd import weights
+    sds = dict(sds, rrdb=weights.generate_state_dict("rrdb"), bisenet=weights.generate_state_dict("bisenet"))
+    one("c3_full_no_enhance", "BASELINE configs[2] without enhancement: detect + align + BiSeNet parse", 5, 2,
+        full=True, batch=32, size=1024, precision="f16x3", enhance="none")
+    one("c3_full_enhance_all", "configs[2] with RRDB on EVERY image (worst case), batch reduced to 2: the enhancer "
+        "costs ~37.6 TFLOP per 1024x1024 image", 2, 1, full=True, batch=2, size=1024, precision="f16x3", enhance="all")
+    one("c3_full_enhance_rule", "configs[2] with the reference's face-area gate (rrdb.py:124-140), batch 8", 2, 1,
+        full=True, batch=8, size=1024, precision="f16x3", enhance="rule")
+    one("c2_detect_f32", "headline workload in the exact-fp32 mode (v_mfma_f32_32x32x2_f32, peak 157.3 TFLOP/s)", 5, 2,
+        full=False, batch=64, size=640, precision="f32", enhance="none")
+    return out
 
 
 def main():
@@ -92,121 +279,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from face_crop_plus_amd import weights, align, engine as E
-    from face_crop_plus_amd.retinaface import RetinaFace
+    from face_crop_plus_amd import weights
 
     sd = weights.generate_state_dict("retinaface")
     if dist is not None:
         from face_crop_plus_amd.dist import broadcast_state_dict
         sd = broadcast_state_dict(sd, dev)        # rank 0's weights -> all ranks, one flat RCCL broadcast
-    det = RetinaFace(args.strategy, 0.6).load(dev, sd, args.precision)
-    from face_crop_plus_amd.cropper import landmarks_target
-    tgt = torch.from_numpy(landmarks_target((args.out_size, args.out_size), 0.65)).to(dev)
-
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    images = torch.randint(0, 256, (args.batch, args.size, args.size, 3), generator=g, dtype=torch.uint8).to(dev)
-    face_total = torch.zeros((), dtype=torch.int64, device=dev)
-
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [None]
-    chunks = list(torch.chunk(images, len(streams)))
-    face_total_s = {st: torch.zeros((), dtype=torch.int64, device=dev) for st in streams if st is not None}
-
-    enh = par = None
+    sds = {"retinaface": sd}
     if full:
-        from face_crop_plus_amd.rrdb import RRDBNet
-        from face_crop_plus_amd.bise import BiSeNet
-        if args.enhance != "none":
-            enh = RRDBNet(0.001).load(dev, weights.generate_state_dict("rrdb"), args.precision)
-        par = BiSeNet({"glasses": [6]}, {"eyes": [4, 5]}, 32).load(dev, weights.generate_state_dict("bisenet"),
-                                                                   args.precision)
-
-    graphed = det.graphed(args.batch, args.size, args.size) if args.graph else None
-
-    def step_chunk(imgs, count):
-        nonlocal graphed
-        if graphed is not None:
-            graphed[0].copy_(imgs)
-            graphed[2].replay()
-            res = graphed[1]
-        else:
-            res = det.detect(imgs, max_faces=imgs.shape[0] if args.strategy != "all" else None)
-        if enh is not None:
-            imgs = imgs.clone()                      # enhancement rewrites the batch in place
-            which = list(range(imgs.shape[0]))
-            if args.enhance == "rule":               # rrdb.py:124-140 needs the landmarks on the host
-                nf_h = int(res["face_offset"][-1].item())
-                which = enh.gate(imgs.shape[0], imgs.shape[1], imgs.shape[2], res["landmarks"][:nf_h].cpu().numpy(),
-                                 res["img_idx"][:nf_h].cpu().tolist())
-            enh.enhance_u8(imgs, which)
-        crops, ok, _ = align.crop_align(imgs, res["img_idx"], res["landmarks"], tgt,
-                                        (args.out_size, args.out_size), 0)
-        if par is not None:
-            par.parse(crops)                         # label maps + class histograms stay on the device
-        if count:
-            nf = torch.clamp(res["face_offset"][-1].to(torch.int64), max=res["max_faces"])
-            valid = (torch.arange(res["max_faces"], device=dev) < nf) & (ok != 0)
-            return crops, valid.sum()
-        return crops, None
-
-    def step(count=True):
-        """One pass of the hot path over the batch.  With --streams S the batch is split into S
-        independent sub-batches on S HIP streams, so one sub-batch's tail wave of workgroups
-        overlaps the next one's head (the path has no cross-image dependency)."""
-        if streams[0] is None:
-            crops, nv = step_chunk(images, count)
-            if count:
-                face_total.add_(nv)
-            return crops
-        cur = torch.cuda.current_stream()
-        outs = []
-        for st, imgs in zip(streams, chunks):
-            if not args.free_running:
-                st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                outs.append(step_chunk(imgs, count))
-                if count and args.free_running:
-                    face_total_s[st].add_(outs[-1][1])
-        if args.free_running:
-            return [c for c, _ in outs]          # the streams stay de-phased, like process_dir's GPU workers
-        for st in streams:
-            cur.wait_stream(st)
-        if count:
-            for _, nv in outs:
-                face_total.add_(nv)
-        return [c for c, _ in outs]
-
-    # one untimed initialisation pass (lazy module loads, per-shape tile tuning), then the W warm-up steps, which are
-    # identical to the timed steps
-    E.Autotune.enabled = not args.no_autotune
-    step(True)
-    torch.cuda.synchronize()
-    E.Autotune.enabled = False
-    for _ in range(args.warmup):
-        step(True)
-    torch.cuda.synchronize()
-    face_total.zero_()
-    # roofline evidence: HIP events around every conv launch of the timed steps themselves, on the launch stream
-    # (one event pair costs ~2 us of host time; --no-live-roofline measures one extra step after the timed region
-    # instead, as do --graph / --streams, whose launches cannot carry per-launch events)
-    live = rank == 0 and not args.no_live_roofline and graphed is None and streams[0] is None
-    if live:
-        E.ConvStats.timing = []
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for v in face_total_s.values():
-        v.zero_()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    for v in face_total_s.values():
-        face_total.add_(v)
-    faces = face_total.clone()
+        sds["rrdb"], sds["bisenet"] = weights.generate_state_dict("rrdb"), weights.generate_state_dict("bisenet")
+    p = Pipeline(dev, sd, full=full, batch=args.batch, size=args.size, out_size=args.out_size, strategy=args.strategy,
+                 precision=args.precision, enhance=args.enhance if full else "none", streams=args.streams,
+                 seed=1234 + rank, graph=args.graph, sd_enh=sds.get("rrdb"), sd_par=sds.get("bisenet"))
+    live = rank == 0 and args.streams <= 1 and not args.graph
+    elapsed, faces = time_pipeline(p, args.steps, args.warmup, autotune=not args.no_autotune, dist=dist, live_events=live)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -214,51 +300,17 @@ def main():
     elapsed = float(el.item())
     total_faces = int(faces.item())
 
-    # ---- roofline of the dominant kernel (conv engine): per-launch HIP events on the launch stream
-    roofline = None
+    roofline = cpu_baseline = extra = None
     if rank == 0:
-        nsteps = args.steps
-        if not live:
-            E.ConvStats.timing = []
-            graphed_saved, graphed = graphed, None      # per-launch events need the eager launches
-            for imgs in chunks:                         # sub-batches one after the other on ONE stream: kernels that
-                step_chunk(imgs, False)                 # share the device would inflate each other's durations
-            graphed = graphed_saved
-            torch.cuda.synchronize()
-            nsteps = 1
-        conv_ms = sum(a.elapsed_time(b) for a, b, _ in E.ConvStats.timing) / nsteps
-        conv_flops = sum(f for _, _, f in E.ConvStats.timing) / nsteps
-        launches = len(E.ConvStats.timing) // nsteps
-        E.ConvStats.timing = None
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_conv.json")) \
-            if os.path.isdir(os.path.join(ROOT, "profiles")) else []
-        prof = [f for f in prof if ("f16x3" in f) == (args.precision == "f16x3")]
-        if prof and args.batch == 64 and args.size == 640:
-            # HBM bytes per conv launch from the committed rocprofv3 --pmc passes of this same command
-            with open(os.path.join(ROOT, "profiles", prof[-1])) as f:
-                traffic = round(json.load(f)["hbm_bytes_per_launch"])
-            traffic_src = "profiles/" + prof[-1]
-        split = args.precision == "f16x3"
-        peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-        roofline = {"bound": "mfma",
-                    "kernel": ("conv_igemm_f16x3 (3x v_mfma_f32_32x32x16_f16 per product: x = hi + lo split)" if split
-                               else "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)"),
-                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4),
-                    # the split path executes 3 matrix FLOP per algorithmic FLOP: utilisation of the f16 pipe
-                    "executed_frac": round(achieved * (3 if split else 1) / peak, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per conv launch (PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
-                    "traffic_source": traffic_src,
-                    "measured": ("HIP events around every conv launch of the timed steps" if live
-                                 else "HIP events around every conv launch of one extra single-stream pass over the batch after the timed region"),
-                    "launches_per_step": launches, "algorithmic_gflop_per_step": round(conv_flops / 1e9, 2),
-                    "avg_launch_ms": round(conv_ms / launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
-
-    cpu_baseline = None
+        roofline = conv_roofline(p, args.steps if live else args.roofline_steps, live)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(sd, images[:32].cpu(), args, tgt.cpu().numpy())
+        cpu_baseline = run_cpu_baseline(sd, p.images[:32].cpu(), args, p.tgt.cpu().numpy())
+    describe = p.describe()
+    if rank == 0 and world == 1 and not args.no_extra and not full:
+        del p
+        gc.collect()
+        torch.cuda.empty_cache()
+        extra = run_extra(dev, sds, args)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -269,17 +321,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3" if args.precision == "f16x3" else "f32",
             "data": "synthetic (uniform uint8 images resident in HBM; seeded random-init weights; file I/O excluded)",
-            "config": {"workload": (f"full pipeline (detect + RRDB enhance[{args.enhance}] + align + BiSeNet parse)" if full
-                                    else "RetinaFace detect + 5-pt align/crop") +
-                                   f", batch={args.batch}/GPU synthetic "
-                                   f"{args.size}x{args.size} RGB, strategy={args.strategy}, det_threshold=0.6, "
-                                   f"output {args.out_size}x{args.out_size}" +
-                                   (f", {len(streams)} HIP streams x {args.batch // len(streams)} images" if len(streams) > 1 else ""),
+            "config": {"workload": describe,
                        "global_batch": args.batch * world, "image_size": args.size, "parallelism": f"dp{world}",
                        "faces_per_step": total_faces / max(args.steps, 1),
                        "images_per_s": round(args.batch * world * args.steps / elapsed, 2)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if extra is not None:
+            line["extra"] = extra
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 
 import os
+import threading
 
 import numpy as np
 import torch
@@ -37,6 +38,12 @@ class RetinaFace:
         self._p = None
         self.precision = 0
         self.fused_stem = os.environ.get("FCP_FUSED_STEM", "1") != "0"   # fp16x3 path: uint8 -> stem + pool in one launch
+        # The network runs on the two halves of a batch concurrently, on two HIP streams: the tail wave of one
+        # half's launch (layers 3-4 fill only ~78 % of their last round of workgroups) overlaps the head of the
+        # other's.  Images are independent, so the result is bit-identical to the single-stream pass.
+        self.streams = int(os.environ.get("FCP_DET_STREAMS", "2"))
+        self.min_images_per_stream = 8
+        self._tls = threading.local()
 
     # ------------------------------------------------------------------ load
     def load(self, device: str | torch.device = "cuda:0", weights=None, precision=None):
@@ -113,9 +120,9 @@ class RetinaFace:
         return p
 
     # --------------------------------------------------------------- forward
-    def forward_heads(self, x4: E.Act | None, images_u8: torch.Tensor | None = None):
+    def forward_heads(self, x4: E.Act | None, images_u8: torch.Tensor | None = None, heads_out=None):
         """NHWC4 (RGB - mean) — or, on the fp16x3 path, the uint8 batch itself — -> three fused head maps
-        (n, h/8|16|32, w/.., 32)."""
+        (n, h/8|16|32, w/.., 32).  ``heads_out``: optional three pre-allocated fp32 views to write them into."""
         p = self._p
         # fp16x3 path: activations between convs live in the "split32" format (hi/lo binary16 planes per 32
         # channels, same bytes as fp32) so every consumer conv copies its operand instead of converting it
@@ -160,7 +167,36 @@ class RetinaFace:
             E.conv(p[f"ssh{k}.ab"], ft, s.slice(0, 192), act_slope=0.0)
             E.conv(p[f"ssh{k}.cd"], s.slice(0, 64), s.slice(256, 128), act_slope=0.0)
             E.conv(p[f"ssh{k}.e"], s.slice(320, 64), s.slice(192, 64), act_slope=0.0)
-            heads.append(E.conv(p[f"head{k}"], s.slice(64, 256)))      # fp32 out: the decode kernel reads it
+            heads.append(E.conv(p[f"head{k}"], s.slice(64, 256),      # fp32 out: the decode kernel reads it
+                                None if heads_out is None else heads_out[k - 1]))
+        return heads
+
+    def _side_streams(self, dev, k):
+        """k HIP streams of the calling host thread (process_dir's GPU workers each get their own set)."""
+        have = self._tls.__dict__.setdefault("streams", {})
+        key = (dev.index, k)
+        if key not in have:
+            have[key] = [torch.cuda.Stream(device=dev) for _ in range(k)]
+        return have[key]
+
+    def _forward_heads_split(self, images_u8: torch.Tensor):
+        """``forward_heads`` of a uint8 batch, its ``self.streams`` contiguous sub-batches enqueued on side streams
+        that fork from and re-join the caller's stream; every sub-batch writes its rows of the shared head maps."""
+        n, h, w, _ = images_u8.shape
+        k = min(self.streams, n // max(1, self.min_images_per_stream))
+        if k < 2 or torch.cuda.is_current_stream_capturing():
+            return self.forward_heads(None, images_u8)
+        dev = images_u8.device
+        heads = [E.Act.empty(n, -(-h // s), -(-w // s), 32, dev) for s in (8, 16, 32)]
+        cur = torch.cuda.current_stream(dev)
+        bounds = [n * i // k for i in range(k + 1)]
+        side = self._side_streams(dev, k)
+        for st, a, b in zip(side, bounds[:-1], bounds[1:]):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                self.forward_heads(None, images_u8[a:b], [E.Act(hd.buf[a:b]) for hd in heads])
+        for st in side:
+            cur.wait_stream(st)
         return heads
 
     # ---------------------------------------------------------------- detect
@@ -181,7 +217,7 @@ class RetinaFace:
         if fused:
             images_u8 = images_u8.contiguous()
             (n, h, w), dev = images_u8.shape[:3], images_u8.device
-            heads = self.forward_heads(None, images_u8)
+            heads = self._forward_heads_split(images_u8)
         else:
             n, h, w = x4.n, x4.h, x4.w
             dev = x4.buf.device

@@ -189,7 +189,8 @@ def test_c3_full_pipeline_with_enhance(tmp_path, device):
     from face_crop_plus_amd.batch import build_batch
     src = tmp_path / "in"
     src.mkdir()
-    imgs = [_photo_like(1024, 1024, 30 + i) for i in range(2)]
+    rng = np.random.default_rng(30)          # i.i.d. noise: what the seeded random-init detector fires on
+    imgs = [rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8) for _ in range(2)]
     for i, im in enumerate(imgs):
         Image.fromarray(im).save(src / f"im{i}.png")
     w = {k: weights.generate_state_dict(k) for k in ("retinaface", "rrdb", "bisenet")}

@@ -115,3 +115,28 @@ def test_degenerate_image_sizes_vs_oracle(hw, sd, device):
     lm, idx = RetinaFace("all", 0.5).load(device, sd).predict(img)
     lr, ir = R.predict(img.permute(0, 3, 1, 2).float(), sd, "all", 0.5)
     assert list(idx) == list(ir) and len(idx) > 0 and np.abs(lm - lr).max() < 2e-3
+
+
+@pytest.mark.parametrize("n,h,w", [(16, 160, 192), (19, 100, 136), (64, 256, 256)])
+def test_two_stream_split_is_bit_identical(n, h, w, sd, device):
+    """Product default: the network runs over the two halves of the batch on two HIP streams (tile-quantisation
+    tails overlap).  Must not change a single bit of any output, for even, odd and non-multiple-of-32 geometries."""
+    from face_crop_plus_amd.retinaface import RetinaFace
+    g = torch.Generator().manual_seed(n)
+    img = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8).to(device)
+    det = RetinaFace("all", 0.55).load(device, sd)
+    assert det.streams == 2
+    res2 = det.detect(img)
+    det.streams = 1
+    res1 = det.detect(img)
+    torch.cuda.synchronize()
+    for a, b in zip(res1["heads"], res2["heads"]):
+        assert torch.equal(a.buf, b.buf)
+    for k in ("landmarks", "img_idx", "face_offset", "cand_count", "keep_count", "sel_count"):
+        assert torch.equal(res1[k], res2[k]), k
+    assert int(res1["face_offset"][-1]) > n
+    det.streams = 3                                     # uneven three-way split
+    det.min_images_per_stream = 4
+    res3 = det.detect(img)
+    torch.cuda.synchronize()
+    assert torch.equal(res1["landmarks"], res3["landmarks"]) and torch.equal(res1["face_offset"], res3["face_offset"])
