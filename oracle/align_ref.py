@@ -26,6 +26,12 @@ They are checked by self-consistency properties in tests/test_align_oracle.py
 (LSQ optimality, exact recovery of known similarities, identity / integer
 translations reproducing source bytes, documented border patterns, <= 1 LSB
 from a float64 bilinear evaluation).
+
+``estimate_transform_cv_sequence`` restates the SEQUENCE OpenCV actually runs (minimal-sample seed, then
+``refineIters`` = 10 Levenberg-Marquardt iterations of calib3d's LMSolver) instead of its fixed point, so that
+the distance between the two is a measured number rather than an argument: tests/test_align_oracle.py bounds
+max |dM| over 10^4 random 5-point sets and counts flipped crop bytes (DESIGN.md §4 quotes both).  It stays
+"parity unpinned" — the restatement of LMSolver is from OpenCV's published source, not from a cv2 run.
 """
 from __future__ import annotations
 
@@ -90,6 +96,121 @@ def estimate_transform(src, dst, allow_skew=False):
         c = (sxY * syy - syY * sxy) / det; e = (syY * sxx - sxY * sxy) / det
         m = np.array([[a, b, MX - a * mx - b * my], [c, e, MY - c * mx - e * my]])
     return m if np.isfinite(m).all() else None
+
+
+def _seed_model(s, d, idx, allow_skew):
+    """Minimal-sample model: 2 points -> similarity (AffinePartial2DEstimatorCallback::runKernel), 3 points ->
+    affine (Affine2DEstimatorCallback::runKernel).  Returns the parameter vector LM refines:
+    (a, b, tx, ty) for [[a, -b, tx], [b, a, ty]]  or  (h0..h5) for [[h0, h1, h2], [h3, h4, h5]]."""
+    if not allow_skew:
+        z = complex(*s[idx[0]]) - complex(*s[idx[1]])
+        Z = complex(*d[idx[0]]) - complex(*d[idx[1]])
+        if z == 0:
+            return None
+        q = Z / z                                           # a + ib
+        t = complex(*d[idx[0]]) - q * complex(*s[idx[0]])
+        return np.array([q.real, q.imag, t.real, t.imag])
+    A = np.array([[s[i, 0], s[i, 1], 1.0] for i in idx])
+    if abs(np.linalg.det(A)) < 1e-12:
+        return None
+    return np.concatenate([np.linalg.solve(A, d[list(idx), 0]), np.linalg.solve(A, d[list(idx), 1])])
+
+
+def _residual_jacobian(h, s, d, allow_skew):
+    """AffinePartial2DRefineCallback / Affine2DRefineCallback::compute: reprojection error of every inlier
+    (interleaved x, y) and its Jacobian — both are LINEAR in h."""
+    x, y = s[:, 0], s[:, 1]
+    k = len(s)
+    if not allow_skew:
+        J = np.zeros((2 * k, 4))
+        J[0::2] = np.stack([x, -y, np.ones(k), np.zeros(k)], 1)
+        J[1::2] = np.stack([y, x, np.zeros(k), np.ones(k)], 1)
+    else:
+        J = np.zeros((2 * k, 6))
+        J[0::2, 0], J[0::2, 1], J[0::2, 2] = x, y, 1.0
+        J[1::2, 3], J[1::2, 4], J[1::2, 5] = x, y, 1.0
+    r = J @ h - d.reshape(-1)
+    return r, J
+
+
+def _lm_solver(h, s, d, allow_skew, max_iters=10, eps=float(np.finfo(np.float32).eps)):
+    """cv::LMSolver (calib3d/levmarq.cpp, LMSolverImpl::run) restated: lambda starts at 1 on diag(JtJ), is halved
+    (and dropped to 0 below 0.75) when the gain ratio R > 0.75, raised by nu in [2, 10] when R < 0.25; a step is
+    accepted iff it lowers the squared error; stops after max_iters or when |step|_inf or |residual|_inf < eps.
+    Returns (h, iterations used, trace of the accepted squared errors)."""
+    x = np.asarray(h, np.float64).copy()
+    r, J = _residual_jacobian(x, s, d, allow_skew)
+    S = float(r @ r)
+    A, v = J.T @ J, J.T @ r
+    D = np.diag(A).copy()
+    lam, lc, it, trace = 1.0, 0.75, 0, [S]
+    while True:
+        Ap = A + np.diag(lam * D)
+        try:
+            step = np.linalg.solve(Ap, v)
+        except np.linalg.LinAlgError:
+            return None, it, trace
+        xd = x - step
+        rd, _ = _residual_jacobian(xd, s, d, allow_skew)
+        Sd = float(rd @ rd)
+        dS = float(step @ (2 * v - A @ step))
+        R = (S - Sd) / (dS if abs(dS) > np.finfo(np.float64).eps else 1.0)
+        if R > 0.75:
+            lam *= 0.5
+            if lam < lc:
+                lam = 0.0
+        elif R < 0.25:
+            t = float(step @ v)
+            nu = (Sd - S) / (t if abs(t) > np.finfo(np.float64).eps else 1.0) + 2
+            nu = min(max(nu, 2.0), 10.0)
+            if lam == 0:
+                inv_diag = np.abs(np.diag(np.linalg.inv(A)))
+                lam = lc = 1.0 / max(float(inv_diag.max()), np.finfo(np.float64).eps)
+                nu *= 0.5
+            lam *= nu
+        if Sd < S:
+            S, x = Sd, xd
+            r, J = _residual_jacobian(x, s, d, allow_skew)
+            A, v = J.T @ J, J.T @ r
+            trace.append(S)
+        it += 1
+        if not (it < max_iters and np.abs(step).max() >= eps and np.abs(r).max() >= eps):
+            break
+    return x, it, trace
+
+
+def estimate_transform_cv_sequence(src, dst, allow_skew=False, seed=None, refine_iters=10, return_info=False):
+    """cv::estimateAffinePartial2D / estimateAffine2D as the SEQUENCE OpenCV runs for the reference's call
+    (cropper.py:515-527: method RANSAC, ransacReprojThreshold = inf, refineIters = 10; calib3d/ptsetreg.cpp):
+
+    1. RANSAC draws one minimal sample (2 points / 3 for the affine form).  With an infinite threshold every
+       point is an inlier of that first model, so the iteration count collapses to zero and the sample's model
+       is "the best".  ``seed``: the sample's point indices (default: the first non-degenerate one in index
+       order — which sample cv::RNG draws is irrelevant, the result below does not depend on it; the tests run
+       every possible sample).
+    2. 10 iterations of LMSolver on the reprojection error of all inliers, starting from that model.
+
+    -> 2x3 float64 (or None)."""
+    s = np.asarray(src, np.float32).astype(np.float64)
+    d = np.asarray(dst, np.float32).astype(np.float64)
+    if not (np.isfinite(s).all() and np.isfinite(d).all()):
+        return None
+    import itertools
+    m = 3 if allow_skew else 2
+    samples = [tuple(seed)] if seed is not None else list(itertools.combinations(range(len(s)), m))
+    h0 = None
+    for idx in samples:                       # RANSAC re-draws while the sample is degenerate
+        h0 = _seed_model(s, d, idx, allow_skew)
+        if h0 is not None and np.isfinite(h0).all():
+            break
+        h0 = None
+    if h0 is None:
+        return None
+    h, iters, trace = _lm_solver(h0, s, d, allow_skew, refine_iters)
+    if h is None or not np.isfinite(h).all():
+        return None
+    M = np.array([[h[0], -h[1], h[2]], [h[1], h[0], h[3]]]) if not allow_skew else h.reshape(2, 3)
+    return (M, iters, trace) if return_info else M
 
 
 def _cv_round(v):
