@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_f32p = C.c_void_p
 _lib = None
@@ -40,10 +40,18 @@ class ConvDesc(C.Structure):
 CONV_FLAT_ADDR = 1   # fcp_conv_desc.flags: FCP_CONV_FLAT_ADDR
 
 
+class ChainDesc(C.Structure):
+    """Mirror of ``fcp_chain_desc``."""
+    _fields_ = [(k, C.c_void_p) for k in ("t1", "w2", "ws2", "b2", "w3", "ws3", "b3", "res", "out", "w1n", "ws1n",
+                                          "b1n", "t1n")] + \
+               [(k, C.c_int32) for k in ("n", "h", "w", "c", "cn", "t1_ld", "res_ld", "out_ld", "t1n_ld")]
+
+
 # name -> argtypes; every function returns int (0 = ok)
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 SIGNATURES = {
     "fcp_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P],
+    "fcp_bottleneck_chain_f16x3": [C.POINTER(ChainDesc), _P],
     "fcp_u8_to_nhwc4_f32": [_P, _P, _L, C.POINTER(C.c_float), _F, _P],
     "fcp_f32nchw_to_nhwc4_f32": [_P, _P, _I, _I, _I, C.POINTER(C.c_float), _F, _P],
     "fcp_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

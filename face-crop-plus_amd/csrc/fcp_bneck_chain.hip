@@ -1,0 +1,489 @@
+// Fused ResNet bottleneck chain (fp16x3 path, split32 tensors), 64-channel bottlenecks (ResNet-50 layer 1):
+//
+//     t2  = relu(bn2(conv2_3x3(t1)))                     64 -> 64      (never leaves the workgroup)
+//     out = relu(bn3(conv3_1x1(t2)) + x)                 64 -> 256     (written once)
+//     t1' = relu(bn1'(conv1'_1x1(out)))                  256 -> CN     (the NEXT block's conv1: CN = 64, or 128 for
+//                                                                       layer2.0.conv1)
+//
+// i.e. torchvision's Bottleneck.forward (retinaface.py:93-99 builds the body from it) from conv2 of block b to
+// conv1 of block b+1.  Unfused, those three launches move  t1 + 2 t2 + 2 t2.. = 6.7 GB per block through HBM at
+// the bench size (64 x 160 x 160 px: x and out are 1.68 GB each at 4 B per element) and run at the HBM rate;
+// fused, a workgroup reads its t1 tile (+ halo, from L2) and its x tile, writes out and t1':  4.2 GB.
+//
+// One 256-thread workgroup owns 128 consecutive output pixels; two workgroups share a CU (80 KiB of LDS each), so
+// one computes while the other waits on memory.
+//
+//   phase 1   implicit GEMM 128 x 64 x 576 exactly as conv_igemm_f16x3_dma<64, 2> (both operands by LDS-DMA, two
+//             stages, taps fastest), epilogue -> T2 in LDS as the split32 operand image [2 slices][128 rows][128 B].
+//   chunks    for each group j of 32 output channels of conv3 (8 groups):
+//               phase 2  acc2[128 x 32]  = T2 . W3[j]^T                (K = 64; W3 group by LDS-DMA, double-buffered)
+//               epilogue out[:, j] = relu(acc2 * ws3 + b3 + x[:, j]) -> HBM, and -> T3 in LDS (operand image)
+//               phase 3  acc3[128 x CN] += T3 . W1'[:, j]^T            (K slice j of conv1'; by LDS-DMA)
+//   epilogue  t1' = relu(acc3 * ws1 + b1) -> HBM.
+//
+// Arithmetic is that of the stand-alone kernels, instruction for instruction (al*bh + ah*bl + ah*bh per k-half,
+// K slices in ascending order, the same fp32 epilogue expressions, the same hi/lo split of every stored tensor), so
+// out and t1' are BIT-IDENTICAL to running the three convolutions separately (tests/test_chain_gpu.py).
+#include "fcp_conv_common.h"
+
+using namespace fcp_conv;
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct ChainK {
+  const float* t1;  unsigned t1_bytes;  int t1_ld;
+  const float* w2;  unsigned w2_bytes;  const float* ws2;  const float* b2;
+  const float* w3;  unsigned w3_bytes;  const float* ws3;  const float* b3;
+  const float* res; int res_ld;
+  float* out;       int out_ld;
+  const float* w1n; unsigned w1n_bytes; const float* ws1n; const float* b1n;
+  float* t1n;       int t1n_ld;
+  int n, h, w, M;
+  int nt_store;
+};
+
+constexpr int C = 64;                 // bottleneck width
+constexpr int ROWB = 128;             // bytes per LDS operand row: 32 hi + 32 lo binary16
+constexpr int STAGE = (BM + C) * ROWB;          // 24 KiB: one phase-1 stage (A rows then B rows)
+constexpr int R0_BYTES = 2 * STAGE;             // 48 KiB region: phase-1 stages | epilogue tiles | chunk buffers
+constexpr int T2_OFF = R0_BYTES;                // 32 KiB: conv2's output tile as operand image
+constexpr int LDS_BYTES = R0_BYTES + BM * C * 4;   // 80 KiB -> two workgroups per CU
+constexpr int CT_OFF = 0;                       // chunk loop: 128 x 32 fp32 epilogue tile, rewritten in place as T3 (16 KiB)
+constexpr int W1B_OFF = 16384;                  // chunk loop: K slice j of conv1' (CN rows x 128 B, <= 16 KiB)
+constexpr int W3B_OFF = 32768;                  // chunk loop: conv3 filter group, 2 x 8 KiB (double buffer)
+constexpr int NCH = 4 * C / 32;                 // 8 groups of 32 conv3 filters
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
+
+template <int CN>
+__global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
+  constexpr int TN3 = CN / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+
+  const int nb = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+  const int tile_m = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int lrow = tid >> 3;                                     // 0..31 (+32 i)
+  const int csrc = (tid & 7) ^ swz(lrow);                        // source chunk of LDS position tid & 7
+  const int l31 = lane & 31, half = lane >> 5;
+  const int rsw = swz(l31);
+  int offH[2], offL[2];                                          // fragment chunk offsets inside a 128-byte row, per k-half
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    offH[s] = ((2 * s + half) ^ rsw) << 4;
+    offL[s] = ((4 + 2 * s + half) ^ rsw) << 4;
+  }
+  const int hw = p.h * p.w;
+
+  // =========================================================================================== phase 1: 3x3 conv
+  f32x16 acc1[2];
+  {
+    constexpr int A_LD = BM / 32, B_LD = C / 32;
+    const int wm = wave / 2, wn = wave % 2;                      // 2 x 2 waves of 64 x 32
+    TapPiece tp[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int m = tile_m * BM + lrow + 32 * i;
+      unsigned pbase = 0;
+      int hi0 = -(1 << 28), wi0 = 0;
+      if (m < p.M) {
+        const int ni = m / hw;
+        const int rem = m - ni * hw;
+        const int ho = rem / p.w;
+        pbase = (unsigned)(ni * hw);
+        hi0 = ho - 1;
+        wi0 = rem - ho * p.w - 1;
+      }
+      tp[i].base = ((pbase + (unsigned)(hi0 * p.w + wi0)) * (unsigned)p.t1_ld + (unsigned)(csrc * 4)) * 4u;
+      tp[i].mask = 0u;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const bool ok = (unsigned)(hi0 + q / 3) < (unsigned)p.h && (unsigned)(wi0 + q % 3) < (unsigned)p.w;
+        tp[i].mask |= ok ? (1u << q) : 0u;
+      }
+    }
+    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t1), 0, p.t1_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2), 0, p.w2_bytes, 0x00020000);
+    unsigned woff[B_LD];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((lrow + 32 * i) * (9 * C) + csrc * 4) * 4);
+    unsigned rowoff[A_LD];
+    auto set_tap = [&](int tap, int kh_i, int kw_i) {
+      const unsigned tapoff = (unsigned)((kh_i * p.w + kw_i) * p.t1_ld) * 4u;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) rowoff[i] = ((tp[i].mask >> tap) & 1u) ? tp[i].base + tapoff : 0xFFFFFFFFu;
+    };
+    int tap = 0, kh_i = 0, kw_i = 0, c0 = 0;
+    auto advance = [&]() {
+      ++tap;
+      if (++kw_i >= 3) {
+        kw_i = 0;
+        if (++kh_i >= 3) { kh_i = 0; tap = 0; c0 += BK; }
+      }
+      set_tap(tap, kh_i, kw_i);
+    };
+    auto dma_slice = [&](int kt, int stage) {
+      char* a = lds + stage * STAGE + wave_u * 8 * ROWB;
+      char* b = a + BM * ROWB;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const unsigned ro = rowoff[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * i * ROWB), 16,
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 32 * i * ROWB), 16,
+                                                 (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc1[i][e] = 0.f;
+
+    const int aoff = (wm * 64 + l31) * ROWB;
+    const int boff = BM * ROWB + (wn * 32 + l31) * ROWB;
+    constexpr int KT = 9 * C / 32;                               // 18 K slices
+    set_tap(0, 0, 0);
+    dma_slice(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+      const char* Ab = lds + stage * STAGE + aoff;
+      const char* Bb = lds + stage * STAGE + boff;
+      f16x8 ah[2][2], al[2][2], bh[2], bl[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[s][i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * ROWB + offH[s]);
+          al[s][i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * ROWB + offL[s]);
+        }
+        bh[s] = *reinterpret_cast<const f16x8*>(Bb + offH[s]);
+        bl[s] = *reinterpret_cast<const f16x8*>(Bb + offL[s]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < KT) {
+        advance();
+        dma_slice(kt + 1, stage ^ 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s], acc1[i], 0, 0, 0);
+          acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s], acc1[i], 0, 0, 0);
+          acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s], acc1[i], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      stage ^= 1;
+    }
+
+    // ---- conv2 epilogue: fp32 tile [128][64] over the dead stages -> relu(acc * ws2 + b2) -> T2 operand image
+    float* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = wm * 64 + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        Cs[row * C + wn * 32 + l31] = acc1[i][rr];
+      }
+    __syncthreads();
+    {
+      const int ccol = (tid & 7) * 8;
+      float ws8[8], b8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ws8[e] = p.ws2[ccol + e];
+        b8[e] = p.b2[ccol + e];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = (tid >> 3) + 32 * g;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * C + ccol);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * C + ccol + 4);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e] * ws8[e] + b8[e];
+          x = x >= 0.f ? x : x * 0.f;
+          v[e] = x * 1.f;
+        }
+        u32x4_t hi, lo;
+        split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+        const int q = (ccol & 31) >> 3, sw = swz(row);
+        char* trow = lds + T2_OFF + (ccol >> 5) * (BM * ROWB) + row * ROWB;
+        *reinterpret_cast<u32x4_t*>(trow + ((q ^ sw) << 4)) = hi;
+        *reinterpret_cast<u32x4_t*>(trow + (((4 + q) ^ sw) << 4)) = lo;
+      }
+    }
+    __syncthreads();                                             // T2 complete; the fp32 tile is dead
+  }
+
+  // ========================================================================== chunk loop: conv3 (+x, relu) and conv1'
+  __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w3), 0, p.w3_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w1n), 0, p.w1n_bytes, 0x00020000);
+  // conv3 filter group j: 32 rows x 2 K slices.  Wave w moves slice w >> 1, rows (w & 1) * 16 + {0..7, 8..15}.
+  const int w3r = (wave_u & 1) * 16 + (lane >> 3);               // + 8 i
+  auto dma_w3 = [&](int j, int buf) {
+    char* dst = lds + W3B_OFF + buf * 8192 + (wave_u >> 1) * 4096 + (wave_u & 1) * 16 * ROWB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = w3r + 8 * i;
+      const unsigned src = (unsigned)((j * 32 + r) * (C * 4) + (wave_u >> 1) * 128 + (((lane & 7) ^ swz(r)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (__attribute__((address_space(3))) void*)(dst + 8 * i * ROWB), 16, (int)src, 0, 0, 0);
+    }
+  };
+  // conv1' K slice j: CN rows.  Wave w moves rows w * CN/4 + 8 i + lane / 8.
+  auto dma_w1 = [&](int j) {
+    char* dst = lds + W1B_OFF + wave_u * (CN / 4) * ROWB;
+#pragma unroll
+    for (int i = 0; i < CN / 32; ++i) {
+      const int r = wave_u * (CN / 4) + 8 * i + (lane >> 3);
+      const unsigned src = (unsigned)(r * (4 * C * 4) + j * 128 + (((lane & 7) ^ swz(r)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + 8 * i * ROWB), 16, (int)src, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc3[TN3];
+#pragma unroll
+  for (int t = 0; t < TN3; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc3[t][e] = 0.f;
+
+  dma_w3(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const char* a2base = lds + T2_OFF + (wave * 32 + l31) * ROWB;   // + slice * BM * ROWB
+  const char* a3base = lds + CT_OFF + (wave * 32 + l31) * ROWB;
+  // epilogue items of this thread: rows erow[it], channel group eq (8 channels) of the 32-channel chunk
+  const int eq = tid & 3;
+  const int erow0 = tid >> 2;                                    // + 64 it
+  const long em0 = (long)tile_m * BM + erow0;
+
+  for (int j = 0; j < NCH; ++j) {
+    // ---- phase 2 operands: T2 (A) and filter group j (B), both K slices
+    f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];                // [slice][k-half]
+    const char* b2base = lds + W3B_OFF + (j & 1) * 8192 + l31 * ROWB;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        ah[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offH[s]);
+        al[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offL[s]);
+        bh[sl][s] = *reinterpret_cast<const f16x8*>(b2base + sl * 4096 + offH[s]);
+        bl[sl][s] = *reinterpret_cast<const f16x8*>(b2base + sl * 4096 + offL[s]);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (j + 1 < NCH) dma_w3(j + 1, (j + 1) & 1);
+    dma_w1(j);
+    // residual x[:, 32 j .. 32 j + 31] of this thread's two items
+    u32x4_t rhi[2], rlo[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      long m = em0 + 64 * it;
+      m = m < p.M ? m : (long)p.M - 1;
+      const char* pb = reinterpret_cast<const char*>(p.res) + m * p.res_ld * 4 + j * 128 + eq * 16;
+      rhi[it] = *reinterpret_cast<const u32x4_t*>(pb);
+      rlo[it] = *reinterpret_cast<const u32x4_t*>(pb + 64);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl][s], bh[sl][s], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[sl][s], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[sl][s], acc2, 0, 0, 0);
+      }
+    // ---- acc2 -> fp32 tile, channel group q of a row stored in the two 16-byte pieces the split32 image of that
+    //      group will occupy (hi piece q ^ sw, lo piece (4 + q) ^ sw): the epilogue rewrites each item in place
+    {
+      const int q = l31 >> 3;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = wave * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        const int piece = ((l31 & 4) ? (4 + q) : q) ^ swz(row);
+        *reinterpret_cast<float*>(lds + CT_OFF + row * ROWB + (piece << 4) + (l31 & 3) * 4) = acc2[rr];
+      }
+    }
+    __syncthreads();
+    // ---- epilogue of conv3 for this chunk: out = relu(acc * ws3 + b3 + x) -> registers (stored below) and T3
+    u32x4_t ohi[2], olo[2];
+    {
+      float ws8[8], b8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ws8[e] = p.ws3[j * 32 + eq * 8 + e];
+        b8[e] = p.b3[j * 32 + eq * 8 + e];
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = erow0 + 64 * it;
+        const int sw = swz(row);
+        char* crow = lds + CT_OFF + row * ROWB;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(crow + ((eq ^ sw) << 4));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(crow + (((4 + eq) ^ sw) << 4));
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        float r[8];
+        join8(rhi[it], rlo[it], r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e] * ws8[e] + b8[e];
+          x += r[e];
+          x = x >= 0.f ? x : x * 0.f;
+          v[e] = x * 1.f;
+        }
+        split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, ohi[it], olo[it]);
+        *reinterpret_cast<u32x4_t*>(crow + ((eq ^ sw) << 4)) = ohi[it];
+        *reinterpret_cast<u32x4_t*>(crow + (((4 + eq) ^ sw) << 4)) = olo[it];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this lane's part of W1' slice j (and W3 group j+1) landed
+    __syncthreads();
+    // ---- phase 3: acc3 += T3 . W1'[:, slice j]^T
+    f16x8 ch[2], cl[2], dh[2][TN3], dl[2][TN3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      ch[s] = *reinterpret_cast<const f16x8*>(a3base + offH[s]);
+      cl[s] = *reinterpret_cast<const f16x8*>(a3base + offL[s]);
+#pragma unroll
+      for (int t = 0; t < TN3; ++t) {
+        dh[s][t] = *reinterpret_cast<const f16x8*>(lds + W1B_OFF + (t * 32 + l31) * ROWB + offH[s]);
+        dl[s][t] = *reinterpret_cast<const f16x8*>(lds + W1B_OFF + (t * 32 + l31) * ROWB + offL[s]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const long m = em0 + 64 * it;
+      if (m < p.M) {
+        char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + j * 128 + eq * 16;
+        if (p.nt_store) {
+          __builtin_nontemporal_store(ohi[it], reinterpret_cast<u32x4_t*>(ob));
+          __builtin_nontemporal_store(olo[it], reinterpret_cast<u32x4_t*>(ob + 64));
+        } else {
+          *reinterpret_cast<u32x4_t*>(ob) = ohi[it];
+          *reinterpret_cast<u32x4_t*>(ob + 64) = olo[it];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < TN3; ++t) {
+        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[s], dh[s][t], acc3[t], 0, 0, 0);
+        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[s], dl[s][t], acc3[t], 0, 0, 0);
+        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[s], dh[s][t], acc3[t], 0, 0, 0);
+      }
+    __syncthreads();                                             // T3, W1' slice and filter group j are dead
+  }
+
+  // ================================================================================ conv1' epilogue -> t1' (HBM)
+  float* Cs = smem;                                              // fp32 tile [128][64], one 64-column half at a time
+#pragma unroll
+  for (int hh = 0; hh < CN / 64; ++hh) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = wave * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        Cs[row * 64 + t * 32 + l31] = acc3[CN == 64 ? t : 2 * hh + t][rr];
+      }
+    __syncthreads();
+    const int ccol = (tid & 7) * 8;
+    const int co = hh * 64 + ccol;
+    float ws8[8], b8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ws8[e] = p.ws1n[co + e];
+      b8[e] = p.b1n[co + e];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = (tid >> 3) + 32 * g;
+      const long m = (long)tile_m * BM + row;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ccol);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ccol + 4);
+      float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e] * ws8[e] + b8[e];
+        x = x >= 0.f ? x : x * 0.f;
+        v[e] = x * 1.f;
+      }
+      if (m >= p.M) continue;
+      u32x4_t hi, lo;
+      split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+      char* ob = reinterpret_cast<char*>(p.t1n) + m * p.t1n_ld * 4 + split_chan_off(co);
+      if (p.nt_store) {
+        __builtin_nontemporal_store(hi, reinterpret_cast<u32x4_t*>(ob));
+        __builtin_nontemporal_store(lo, reinterpret_cast<u32x4_t*>(ob + 64));
+      } else {
+        *reinterpret_cast<u32x4_t*>(ob) = hi;
+        *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int CN>
+int launch(const ChainK& k, hipStream_t s) {
+  FCP_LDS_OPT_IN((&bneck_chain_c64<CN>), LDS_BYTES);
+  hipLaunchKernelGGL((bneck_chain_c64<CN>), dim3(fcp_cdiv(k.M, BM)), dim3(256), LDS_BYTES, s, k);
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t stream) {
+  FCP_REQUIRE(d != nullptr, "chain: null descriptor");
+  FCP_REQUIRE(d->t1 && d->w2 && d->ws2 && d->b2 && d->w3 && d->ws3 && d->b3 && d->res && d->out && d->w1n && d->ws1n &&
+              d->b1n && d->t1n, "chain: null pointer (all three convolutions carry folded-BN bias and filter scales)");
+  FCP_REQUIRE(d->c == 64, "chain: bottleneck width %d not supported (64: ResNet-50 layer 1)", d->c);
+  FCP_REQUIRE(d->cn == 64 || d->cn == 128, "chain: next conv1 must have 64 or 128 filters (got %d)", d->cn);
+  FCP_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "chain: bad sizes");
+  const long M = (long)d->n * d->h * d->w;
+  FCP_REQUIRE(M < (1L << 31), "chain: too many pixels");
+  auto aligned = [](const void* p, int ld) { return ((uintptr_t)p & 127) == 0 && ld % 32 == 0; };
+  FCP_REQUIRE(aligned(d->t1, d->t1_ld) && aligned(d->res, d->res_ld) && aligned(d->out, d->out_ld) && aligned(d->t1n, d->t1n_ld),
+              "chain: tensors are split32 views: 128-byte aligned, channel stride a multiple of 32");
+  FCP_REQUIRE(d->t1_ld >= 64 && d->res_ld >= 256 && d->out_ld >= 256 && d->t1n_ld >= d->cn, "chain: channel strides too small");
+  const unsigned long t1_bytes = (unsigned long)M * d->t1_ld * 4ul;
+  FCP_REQUIRE(t1_bytes < 0xFFFFFFF0ul, "chain: t1 must be below 4 GiB");
+  ChainK k;
+  k.t1 = d->t1; k.t1_bytes = (unsigned)t1_bytes; k.t1_ld = d->t1_ld;
+  k.w2 = reinterpret_cast<const float*>(d->w2); k.w2_bytes = 128u * 9 * 64 * 4; k.ws2 = d->ws2; k.b2 = d->b2;
+  k.w3 = reinterpret_cast<const float*>(d->w3); k.w3_bytes = 256u * 64 * 4; k.ws3 = d->ws3; k.b3 = d->b3;
+  k.res = d->res; k.res_ld = d->res_ld; k.out = d->out; k.out_ld = d->out_ld;
+  k.w1n = reinterpret_cast<const float*>(d->w1n); k.w1n_bytes = 128u * 256 * 4; k.ws1n = d->ws1n; k.b1n = d->b1n;
+  k.t1n = d->t1n; k.t1n_ld = d->t1n_ld;
+  k.n = d->n; k.h = d->h; k.w = d->w; k.M = (int)M;
+  static const int nt_env = getenv("FCP_NT_STORE") ? atoi(getenv("FCP_NT_STORE")) : 1;
+  k.nt_store = nt_env;
+  return d->cn == 64 ? launch<64>(k, (hipStream_t)stream) : launch<128>(k, (hipStream_t)stream);
+}

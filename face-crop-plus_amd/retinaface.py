@@ -41,6 +41,8 @@ class RetinaFace:
         # The network runs on the two halves of a batch concurrently, on two HIP streams: the tail wave of one
         # half's launch (layers 3-4 fill only ~78 % of their last round of workgroups) overlaps the head of the
         # other's.  Images are independent, so the result is bit-identical to the single-stream pass.
+        # conv2 + conv3 of an identity bottleneck and conv1 of the next block in one launch (layer 1; bit-identical)
+        self.fused_chain = os.environ.get("FCP_FUSED_CHAIN", "1") != "0"
         self.streams = int(os.environ.get("FCP_DET_STREAMS", "2"))
         self.min_images_per_stream = 8
         self._tls = threading.local()
@@ -137,8 +139,15 @@ class RetinaFace:
             cat = E.Act.empty(x.n, (x.h + 1) // 2, (x.w + 1) // 2, 2 * x.c, x.buf.device, f)
             x = E.maxpool3x3s2(x, cat.slice(x.c, x.c))
         feats = []
-        for blk in p["blocks"]:
-            o = E.conv(blk["c1"], x, act_slope=0.0, out_fmt=f)
+        blocks, pre = p["blocks"], None
+        for bi, blk in enumerate(blocks):
+            o = pre if pre is not None else E.conv(blk["c1"], x, act_slope=0.0, out_fmt=f)
+            pre = None
+            nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+            if (f and self.fused_chain and blk["ds"] is None and not blk["feat"] and nxt is not None
+                    and E.chain_supported(blk["c2"], blk["c3"], nxt["c1"])):
+                x, pre = E.bottleneck_chain(blk["c2"], blk["c3"], nxt["c1"], o, x)   # pre: next block's conv1 output
+                continue
             if "c3ds" in blk and blk["c2"].stride == 1:
                 E.conv(blk["c2"], o, cat.slice(0, o.c), act_slope=0.0)
                 x = E.conv(blk["c3ds"], cat, act_slope=0.0, out_fmt=f)

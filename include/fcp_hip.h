@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 8
+#define FCP_ABI_VERSION 9
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -115,6 +115,34 @@ typedef struct fcp_conv_desc {
 #define FCP_CONV_FLAT_ADDR 1
 
 int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Fused bottleneck chain (precision 1, split32 tensors): conv2 of ResNet block b, conv3 of block b
+ * with the identity residual, and conv1 of block b + 1, in ONE launch:
+ *     t2  = relu(conv2_3x3(t1) * ws2 + b2)                   c  -> c    (stays in LDS)
+ *     out = relu(conv3_1x1(t2) * ws3 + b3 + res)             c  -> 4c   (written once)
+ *     t1n = relu(conv1n_1x1(out) * ws1n + b1n)               4c -> cn
+ * Replaces torchvision's Bottleneck.forward (the ResNet-50 body retinaface.py:93-99 wraps) from conv2 of one
+ * identity block to conv1 of the next: the 4c-channel tensor crosses HBM twice (residual read, result write)
+ * instead of four times and the c-channel intermediate never leaves the workgroup.  Results are bit-identical
+ * to three fcp_conv2d_nhwc_f32 launches.  Filters are ordinary precision-1 packs (pack_conv): w2
+ * [128][9c] (3x3 / stride 1 / pad 1), w3 [4c][c], w1n [cn padded to 128][4c]; BatchNorm folded, so every conv
+ * has a bias and a per-filter scale.  All tensors are split32 views (n, h, w, *_ld), 128-byte aligned,
+ * *_ld % 32 == 0.  Supported: c = 64 (ResNet-50 layer 1), cn = 64 or 128.
+ * ------------------------------------------------------------------------ */
+typedef struct fcp_chain_desc {
+  const float* t1;    /* conv2's input: c channels */
+  const void* w2;  const float* ws2;  const float* b2;
+  const void* w3;  const float* ws3;  const float* b3;
+  const float* res;   /* identity branch x: 4c channels */
+  float* out;         /* 4c channels */
+  const void* w1n; const float* ws1n; const float* b1n;
+  float* t1n;         /* cn channels */
+  int32_t n, h, w, c, cn;
+  int32_t t1_ld, res_ld, out_ld, t1n_ld;
+} fcp_chain_desc;
+
+int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* desc, fcp_stream_t stream);
 
 /* uint8 NHWC RGB (n,h,w,3) -> fp32 NHWC4 (n,h,w,4): out[c] = (in[c]-sub[c])/div, out[3]=0.
  * Replaces utils.py:222-224 (as_tensor) fused with retinaface.py:450-451 (mean

@@ -1,0 +1,90 @@
+"""Fused bottleneck chain (conv2 -> conv3 + identity -> next conv1) vs the three stand-alone convolutions:
+the fused launch must reproduce them BIT FOR BIT (same K order, same epilogue arithmetic, same hi/lo splits),
+and both must match a torch fp32 reference of the three ops to fp32 roundoff."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bn(c, g):
+    return dict(weight=torch.rand(c, generator=g) * 0.6 + 0.6, bias=torch.randn(c, generator=g) * 0.1,
+                running_mean=torch.randn(c, generator=g) * 0.1, running_var=torch.rand(c, generator=g) + 0.5)
+
+
+def _ref_bn(x, bn):
+    return F.batch_norm(x, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5)
+
+
+@pytest.mark.parametrize("n,h,w,cn", [(2, 37, 45, 64), (1, 16, 16, 128), (3, 64, 50, 128), (1, 5, 3, 64), (4, 160, 160, 64)])
+def test_chain_equals_three_convs(n, h, w, cn, device):
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(n * 1000 + h)
+    w2 = torch.randn(64, 64, 3, 3, generator=g) * (2 / 576) ** 0.5
+    w3 = torch.randn(256, 64, 1, 1, generator=g) * (2 / 64) ** 0.5
+    w1 = torch.randn(cn, 256, 1, 1, generator=g) * (2 / 256) ** 0.5
+    bn2, bn3, bn1 = _bn(64, g), _bn(256, g), _bn(cn, g)
+    bn3["weight"] = bn3["weight"] * 0.4
+    t1 = F.relu(torch.randn(n, 64, h, w, generator=g))
+    x = F.relu(torch.randn(n, 256, h, w, generator=g))
+    with E.default_precision("f16x3"):
+        pc2 = E.pack_conv(w2, None, bn2, 1, 1, device)
+        pc3 = E.pack_conv(w3, None, bn3, 1, 0, device)
+        pc1 = E.pack_conv(w1, None, bn1, 1, 0, device)
+    assert E.chain_supported(pc2, pc3, pc1)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(device)
+    t1a, xa = E.f32_to_split32(E.Act(nhwc(t1))), E.f32_to_split32(E.Act(nhwc(x)))
+    # stand-alone convolutions (every tile choice of the engine gives the same bits)
+    o2 = E.conv(pc2, t1a, act_slope=0.0, out_fmt=1)
+    o3 = E.conv(pc3, o2, act_slope=0.0, res1=xa, res1_pre=True, out_fmt=1)
+    o1 = E.conv(pc1, o3, act_slope=0.0, out_fmt=1)
+    out, t1n = E.bottleneck_chain(pc2, pc3, pc1, t1a, xa)
+    torch.cuda.synchronize()
+    assert torch.equal(out.buf, o3.buf), "fused conv3 output differs from the stand-alone kernels"
+    assert torch.equal(t1n.buf, o1.buf), "fused next-conv1 output differs from the stand-alone kernels"
+    # and against torch fp32
+    r2 = F.relu(_ref_bn(F.conv2d(t1, w2, None, 1, 1), bn2))
+    r3 = F.relu(_ref_bn(F.conv2d(r2, w3), bn3) + x)
+    r1 = F.relu(_ref_bn(F.conv2d(r3, w1), bn1))
+    for got, ref in ((out, r3), (t1n, r1)):
+        err = (got.nchw().cpu() - ref).abs().max().item()
+        assert err <= 3e-5 * float(ref.abs().max()) + 1e-6, err
+
+
+def test_chain_into_channel_slices(device):
+    """Outputs may be channel slices of wider buffers (ld > c); untouched channels stay untouched."""
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(5)
+    n, h, w = 1, 20, 24
+    with E.default_precision("f16x3"):
+        pc2 = E.pack_conv(torch.randn(64, 64, 3, 3, generator=g) / 24, torch.randn(64, generator=g), None, 1, 1, device)
+        pc3 = E.pack_conv(torch.randn(256, 64, 1, 1, generator=g) / 8, torch.randn(256, generator=g), None, 1, 0, device)
+        pc1 = E.pack_conv(torch.randn(64, 256, 1, 1, generator=g) / 16, torch.randn(64, generator=g), None, 1, 0, device)
+    t1w = E.Act(torch.randn(n, h, w, 128, generator=g).to(device))
+    t1w = E.f32_to_split32(t1w)
+    xa = E.f32_to_split32(E.Act(torch.randn(n, h, w, 256, generator=g).to(device)))
+    wide_out = E.Act(torch.full((n, h, w, 320), 7.0, device=device), fmt=1)
+    wide_t1n = E.Act(torch.full((n, h, w, 128), 9.0, device=device), fmt=1)
+    ref_out, ref_t1n = E.bottleneck_chain(pc2, pc3, pc1, t1w.slice(64, 64), xa)
+    E.bottleneck_chain(pc2, pc3, pc1, t1w.slice(64, 64), xa, wide_out.slice(64, 256), wide_t1n.slice(64, 64))
+    torch.cuda.synchronize()
+    assert torch.equal(wide_out.buf[..., 64:320], ref_out.buf) and torch.equal(wide_t1n.buf[..., 64:], ref_t1n.buf)
+    assert float((wide_out.buf[..., :64] - 7.0).abs().max()) == 0 and float((wide_t1n.buf[..., :64] - 9.0).abs().max()) == 0
+
+
+def test_detector_same_bits_with_and_without_chain(device):
+    from face_crop_plus_amd import weights
+    from face_crop_plus_amd.retinaface import RetinaFace
+    det = RetinaFace("all", 0.55).load(device, weights.generate_state_dict("retinaface"))
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (5, 200, 168, 3), generator=g, dtype=torch.uint8).to(device)
+    assert det.fused_chain
+    a = det.detect(img)
+    det.fused_chain = False
+    b = det.detect(img)
+    torch.cuda.synchronize()
+    for ha, hb in zip(a["heads"], b["heads"]):
+        assert torch.equal(ha.buf, hb.buf)
+    assert torch.equal(a["landmarks"], b["landmarks"]) and torch.equal(a["face_offset"], b["face_offset"])
