@@ -42,6 +42,7 @@ struct ChainK {
   float* t1n;       int t1n_ld;
   int n, h, w, M;
   int nt_store;
+  int ablate;   // profiling builds only (FCP_CHAIN_ABLATE): 1 no out stores, 2 no residual loads, 4 no phase-1 loop, 8 no chunk loop
 };
 
 constexpr int C = 64;                 // bottleneck width
@@ -158,7 +159,8 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int stage = 0;
-    for (int kt = 0; kt < KT; ++kt) {
+    const int kt_end = FCP_ABLATE(p, 4) ? 0 : KT;
+    for (int kt = 0; kt < kt_end; ++kt) {
       const char* Ab = lds + stage * STAGE + aoff;
       const char* Bb = lds + stage * STAGE + boff;
       f16x8 ah[2][2], al[2][2], bh[2], bl[2];
@@ -266,18 +268,40 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc3[t][e] = 0.f;
 
-  dma_w3(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
   const char* a2base = lds + T2_OFF + (wave * 32 + l31) * ROWB;   // + slice * BM * ROWB
   const char* a3base = lds + CT_OFF + (wave * 32 + l31) * ROWB;
-  // epilogue items of this thread: rows erow[it], channel group eq (8 channels) of the 32-channel chunk
+  // epilogue items of this thread: rows erow0, erow0 + 64; channel group eq (8 channels) of the 32-channel chunk
   const int eq = tid & 3;
-  const int erow0 = tid >> 2;                                    // + 64 it
+  const int erow0 = tid >> 2;
   const long em0 = (long)tile_m * BM + erow0;
+  long rm[2];                                                    // residual / output pixel of the two items (clamped)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    rm[it] = em0 + 64 * it < p.M ? em0 + 64 * it : (long)p.M - 1;
+    if (FCP_ABLATE(p, 2)) rm[it] = 0;
+  }
+  // The residual x[:, 32 j ..] is requested ONE CHUNK AHEAD (right after chunk j - 1 has consumed its own), so its
+  // HBM round trip spans a whole chunk of matrix work; every wait below is counted so that neither these loads
+  // nor the stores of `out` (issued after them) are ever drained early.  vmem issue order per chunk:
+  //   [top]  W3 group j+1 (2 DMA), W1' slice j (CN/32 DMA)  |  [epilogue]  residual j+1 (4 loads)  |  [phase 3]  out j (4 stores)
+  u32x4_t rhi[2], rlo[2];
+  auto load_res = [&](int j) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const char* pb = reinterpret_cast<const char*>(p.res) + rm[it] * p.res_ld * 4 + j * 128 + eq * 16;
+      rhi[it] = *reinterpret_cast<const u32x4_t*>(pb);
+      rlo[it] = *reinterpret_cast<const u32x4_t*>(pb + 64);
+    }
+  };
+  const int nch = FCP_ABLATE(p, 8) ? 0 : NCH;
+  dma_w3(0, 0);
+  if (nch > 0) load_res(0);
+  float ws_l = p.ws3[l31], b_l = p.b3[l31];                      // this lane's conv3 channel of chunk 0 (MFMA layout: col = lane & 31)
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");               // the filter group has landed; the residual may still fly
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
 
-  for (int j = 0; j < NCH; ++j) {
+  for (int j = 0; j < nch; ++j) {
     // ---- phase 2 operands: T2 (A) and filter group j (B), both K slices
     f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];                // [slice][k-half]
     const char* b2base = lds + W3B_OFF + (j & 1) * 8192 + l31 * ROWB;
@@ -294,16 +318,6 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
     __builtin_amdgcn_sched_barrier(0);
     if (j + 1 < NCH) dma_w3(j + 1, (j + 1) & 1);
     dma_w1(j);
-    // residual x[:, 32 j .. 32 j + 31] of this thread's two items
-    u32x4_t rhi[2], rlo[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      long m = em0 + 64 * it;
-      m = m < p.M ? m : (long)p.M - 1;
-      const char* pb = reinterpret_cast<const char*>(p.res) + m * p.res_ld * 4 + j * 128 + eq * 16;
-      rhi[it] = *reinterpret_cast<const u32x4_t*>(pb);
-      rlo[it] = *reinterpret_cast<const u32x4_t*>(pb + 64);
-    }
     __builtin_amdgcn_sched_barrier(0);
     f32x16 acc2;
 #pragma unroll
@@ -316,51 +330,57 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[sl][s], acc2, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[sl][s], acc2, 0, 0, 0);
       }
-    // ---- acc2 -> fp32 tile, channel group q of a row stored in the two 16-byte pieces the split32 image of that
-    //      group will occupy (hi piece q ^ sw, lo piece (4 + q) ^ sw): the epilogue rewrites each item in place
+    // ---- acc2 * ws3 + b3 (per lane: one channel) -> fp32 tile.  Channel group q of a row is stored in the two
+    //      16-byte pieces the split32 image of that group will occupy (hi piece q ^ sw, lo piece (4 + q) ^ sw),
+    //      so the epilogue rewrites each item in place and needs no extra barrier.
     {
       const int q = l31 >> 3;
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
         const int row = wave * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
         const int piece = ((l31 & 4) ? (4 + q) : q) ^ swz(row);
-        *reinterpret_cast<float*>(lds + CT_OFF + row * ROWB + (piece << 4) + (l31 & 3) * 4) = acc2[rr];
+        *reinterpret_cast<float*>(lds + CT_OFF + row * ROWB + (piece << 4) + (l31 & 3) * 4) = acc2[rr] * ws_l + b_l;
       }
     }
-    __syncthreads();
-    // ---- epilogue of conv3 for this chunk: out = relu(acc * ws3 + b3 + x) -> registers (stored below) and T3
+    if (j + 1 < NCH) {                                           // next chunk's channel constants (L2 hits, a chunk ahead)
+      ws_l = p.ws3[(j + 1) * 32 + l31];
+      b_l = p.b3[(j + 1) * 32 + l31];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue of conv3 for this chunk: out = relu(. + x) -> registers (stored in phase 3) and T3 (in place)
     u32x4_t ohi[2], olo[2];
-    {
-      float ws8[8], b8[8];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = erow0 + 64 * it;
+      const int sw = swz(row);
+      char* crow = lds + CT_OFF + row * ROWB;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(crow + ((eq ^ sw) << 4));
+      const f32x4 b = *reinterpret_cast<const f32x4*>(crow + (((4 + eq) ^ sw) << 4));
+      float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      float r[8];
+      join8(rhi[it], rlo[it], r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        ws8[e] = p.ws3[j * 32 + eq * 8 + e];
-        b8[e] = p.b3[j * 32 + eq * 8 + e];
+        float x = v[e] + r[e];
+        x = x >= 0.f ? x : x * 0.f;
+        v[e] = x * 1.f;
       }
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int row = erow0 + 64 * it;
-        const int sw = swz(row);
-        char* crow = lds + CT_OFF + row * ROWB;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(crow + ((eq ^ sw) << 4));
-        const f32x4 b = *reinterpret_cast<const f32x4*>(crow + (((4 + eq) ^ sw) << 4));
-        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        float r[8];
-        join8(rhi[it], rlo[it], r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = v[e] * ws8[e] + b8[e];
-          x += r[e];
-          x = x >= 0.f ? x : x * 0.f;
-          v[e] = x * 1.f;
-        }
-        split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, ohi[it], olo[it]);
-        *reinterpret_cast<u32x4_t*>(crow + ((eq ^ sw) << 4)) = ohi[it];
-        *reinterpret_cast<u32x4_t*>(crow + (((4 + eq) ^ sw) << 4)) = olo[it];
-      }
+      split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, ohi[it], olo[it]);
+      *reinterpret_cast<u32x4_t*>(crow + ((eq ^ sw) << 4)) = ohi[it];
+      *reinterpret_cast<u32x4_t*>(crow + (((4 + eq) ^ sw) << 4)) = olo[it];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this lane's part of W1' slice j (and W3 group j+1) landed
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (j + 1 < NCH) load_res(j + 1);                            // the registers are free again: next chunk's residual
+    __builtin_amdgcn_sched_barrier(0);
+    // W1' slice j (issued at the top, older than the 4 residual loads just issued) must have landed
+    if (j + 1 < NCH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     // ---- phase 3: acc3 += T3 . W1'[:, slice j]^T
     f16x8 ch[2], cl[2], dh[2][TN3], dl[2][TN3];
 #pragma unroll
@@ -378,7 +398,7 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const long m = em0 + 64 * it;
-      if (m < p.M) {
+      if (m < p.M && !FCP_ABLATE(p, 1)) {
         char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + j * 128 + eq * 16;
         if (p.nt_store) {
           __builtin_nontemporal_store(ohi[it], reinterpret_cast<u32x4_t*>(ob));
@@ -398,8 +418,12 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
         acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[s], dl[s][t], acc3[t], 0, 0, 0);
         acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[s], dh[s][t], acc3[t], 0, 0, 0);
       }
-    __syncthreads();                                             // T3, W1' slice and filter group j are dead
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                                // T3, W1' slice and filter group j are dead
+    __builtin_amdgcn_sched_barrier(0);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   // ================================================================================ conv1' epilogue -> t1' (HBM)
   float* Cs = smem;                                              // fp32 tile [128][64], one 64-column half at a time
@@ -485,5 +509,11 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   k.n = d->n; k.h = d->h; k.w = d->w; k.M = (int)M;
   static const int nt_env = getenv("FCP_NT_STORE") ? atoi(getenv("FCP_NT_STORE")) : 1;
   k.nt_store = nt_env;
+#ifdef FCP_CONV_PROFILING
+  static const int ablate_env = getenv("FCP_CHAIN_ABLATE") ? atoi(getenv("FCP_CHAIN_ABLATE")) : 0;
+  k.ablate = ablate_env;
+#else
+  k.ablate = 0;
+#endif
   return d->cn == 64 ? launch<64>(k, (hipStream_t)stream) : launch<128>(k, (hipStream_t)stream);
 }

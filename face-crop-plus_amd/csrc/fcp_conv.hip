@@ -268,9 +268,9 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   FCP_REQUIRE(d->tile_m == 0 || d->tile_m == 128 || big || halo, "conv: tile_m must be 0/128/256 (or 1: halo-tile 3x3)");
   if (halo)
     FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && !d->in_up2 && d->kh == 3 && d->kw == 3 && d->stride == 1 &&
-                d->pad == 1 && d->cout <= 32 && d->cout % 8 == 0 && !d->in2 &&
+                d->pad == 1 && d->cout <= 64 && d->cout % 8 == 0 && d->cin >= 64 && !d->in2 &&
                 (!d->res1 || (d->res1_h == d->out_h && d->res1_w == d->out_w)),
-                "conv: the halo-tile kernel needs a 3x3 / stride 1 / pad 1 conv with cout <= 32 (cout %% 8 == 0) on the "
+                "conv: the halo-tile kernel needs a 3x3 / stride 1 / pad 1 conv with cin >= 64, cout <= 64 (cout %% 8 == 0) on the "
                 "fp16x3 path with a split32 input, no second source, no resized residual");
   FCP_REQUIRE(d->tile_n == 32 || d->tile_n == 64 || d->tile_n == 128 || (big && d->tile_n == 256),
               "conv: tile_n must be 32/64/128 (or 256 with tile_m 256)");
@@ -384,6 +384,10 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
     const int dma_stages = 2;
 #endif
     if (halo) {
+      k.grid_n = 1;
+      const unsigned long out_bytes = (unsigned long)M * d->out_ld * 4ul;
+      FCP_REQUIRE(out_bytes < 0xFFFFFFF0ul, "conv(halo): the output view must span less than 4 GiB");
+      k.in2_bytes = (unsigned)out_bytes;                // halo launches take no second source: the field carries |out|
       k.w_bytes = (unsigned)((unsigned long)fcp_cdiv(d->cout, 128) * 128ul * k.wrow * 4ul);
       return launch_f16x3_halo(k, s);
     }

@@ -1,18 +1,30 @@
-// fp16x3 3x3 convolution (stride 1, pad 1) for narrow outputs (cout <= 32): halo-tile implicit GEMM.
+// fp16x3 3x3 convolution (stride 1, pad 1) for narrow outputs (cout <= 64): halo-tile implicit GEMM.
 //
 // The generic kernels fetch a 128-byte operand row per output pixel, filter tap and 32-channel slice:
 // with N = 32 output channels that is 20 KiB of LDS-DMA per 6 MFMAs of a wave, and the RRDB dense
-// blocks (rrdb.py / _layers.py:168-200: 276 of the 351 convs have 32 filters) run at the operand-feed
-// limit.  Here a workgroup owns an 8 x 32 patch of output pixels and stages, per 32-channel slice,
-// the (8+2) x (32+2) halo patch ONCE; the nine taps read it at shifted row indices.  Operand traffic
-// per slice drops from 9 x 32 KiB to 43 KiB (+ 36 KiB of filter taps), a whole slice (108 MFMAs per
-// wave) hides one DMA round trip, and there is one barrier per slice.
+// blocks (rrdb.py / _layers.py:168-200: 276 of the 351 convs have 32 filters, 69 have 64) run at the
+// operand-feed limit.  Here a workgroup owns an 8 x 32 patch of output pixels and stages, per 32-channel
+// slice, the (8+2) x (32+2) halo patch ONCE; the nine taps read it at shifted row indices.
 //
-//  * 4 waves; wave w computes image rows 2w, 2w+1 of the patch (two 32x32 MFMA tiles) x 32 filters.
-//  * LDS stage = halo rows [344][128 B] + filter rows [9 taps][32][128 B]; two stages (158 KiB).
-//  * Same arithmetic as the other fp16x3 kernels (al*bh + ah*bl + ah*bh per k-half, channel slices
-//    outer, taps inner) => bit-identical results.
-//  * Fragment reads are inline-asm ds_read_b128 (see fcp_conv_f16x3_big.hip), prefetched one tap ahead.
+//  * 4 waves, one workgroup per CU; wave w computes image rows 2w, 2w+1 of the patch (two 32x32 MFMA
+//    tiles) x 32 filters per pass; cout = 64 runs two passes per slice over the same halo patch.
+//  * LDS: two halo stages [344][128 B] + two filter buffers [9 taps][32][128 B] = 158 KiB.  A "block" =
+//    (slice, pass) = 9 taps = 108 MFMAs per wave, ONE barrier per block; the DMA of the next block's filter
+//    buffer / next slice's halo stage is issued a whole block ahead.
+//  * The nine taps are unrolled: a tap is 12 ds_read_b128 (the NEXT tap's fragments, written into the registers of
+//    the k-half whose six MFMAs have just been issued) + 6 address XORs + 12 MFMAs, with no scalar bookkeeping or
+//    branch in between.  (The first version kept tap / slice / stage as run-time state: rocprof showed 26 % matrix-pipe
+//    utilisation, ~1000 idle cycles per tap in compare / select / branch chains between the MFMA groups.)
+//    Fragment addresses: for a halo row the four 16-byte chunks a lane needs (hi / lo x k-half) differ only in
+//    address bits 5-6, so ONE register per (row offset, kw) pair — 12 per lane — and XOR immediates give all.
+//  * Persistent over tiles (grid = min(tiles, CUs)): a workgroup's tiles form one stream of blocks, refilled two
+//    blocks ahead ACROSS tile boundaries, so a tile starts with its operands already in LDS and its epilogue (fp32
+//    tile in the halo stage that has just died, buffer stores that drop out-of-range pixels) runs while the next
+//    tile's second filter block is in flight.
+//  * Same arithmetic as the other fp16x3 kernels (al*bh + ah*bl + ah*bh per k-half, channel slices outer,
+//    taps inner) => bit-identical results.
+//  * Fragment reads are inline-asm ds_read_b128: the compiler's waitcnt pass would otherwise drain the pending
+//    LDS-DMA (vmcnt(0)) in front of every LDS read (see fcp_conv_f16x3_big.hip).
 #include "fcp_conv_common.h"
 
 #include <type_traits>
@@ -27,55 +39,105 @@ constexpr int TH = 8, TW = 32;            // output patch
 constexpr int HW_ = TW + 2;               // halo patch width (34); height TH + 2 = 10
 constexpr int HROWS = 344;                // 340 halo rows padded to a multiple of 8
 constexpr int ROWB = 128;
-constexpr int A_BYTES = HROWS * ROWB;     // 44032
-constexpr int B_BYTES = 9 * 32 * ROWB;    // 36864
-constexpr int STAGE_B = A_BYTES + B_BYTES;   // 80896
-constexpr int A_LD = 11;                  // DMA instructions per thread: 2752 16-byte pieces / 256 (last: waves 0..2)
+constexpr int A_BYTES = HROWS * ROWB;     // 44032: one halo stage
+constexpr int B_BYTES = 9 * 32 * ROWB;    // 36864: one filter buffer (9 taps x 32 filters)
+constexpr int B_OFF = 2 * A_BYTES;        // filter buffers follow the two halo stages
+constexpr int LDS_TOTAL = 2 * A_BYTES + 2 * B_BYTES;   // 161792
+constexpr int A_LD = 11;                  // halo DMA instructions per thread: 2752 16-byte pieces / 256 (last: waves 0..2)
 
-__device__ __forceinline__ f16x8 lds_read128v(unsigned addr) {
+template <int IMM>
+__device__ __forceinline__ f16x8 lds_read128i(unsigned addr) {
   f16x8 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
   return v;
 }
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
+// epilogue LDS accesses, also inline asm: the next tile's first DMA is in flight while the fp32 tile is staged
+__device__ __forceinline__ void lds_write32(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 lds_read128f(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int TN>   // 32-filter passes per slice: cout <= 32 * TN
 __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
   const int tiles_x = (p.out_w + TW - 1) / TW, tiles_y = (p.out_h + TH - 1) / TH;
-  const int nb = gridDim.x;
-  const int bid = blockIdx.x;
-  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tx = logical % tiles_x;
-  const int ty = (logical / tiles_x) % tiles_y;
-  const int ni = logical / (tiles_x * tiles_y);
-  const int y0 = ty * TH, x0 = tx * TW;
+  const int ntiles = p.n * tiles_x * tiles_y;
+  // persistent workgroups; XCD x (= blockIdx & 7) walks a contiguous range of tiles, so neighbouring patches
+  // (which share halo rows) meet in one L2
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int per_x = (ntiles + 7) / 8;
+  const int xcd = bid & 7, slot = bid >> 3, slots = (nb + 7 - xcd) / 8;   // workgroups of this XCD: slot = 0..slots-1
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = tid >> 3;                          // 0..31 (+32 i)
   const int csrc = (tid & 7) ^ swz(lrow);             // rows differ by multiples of 32: one swizzle per thread
+  const int xl = lane & 31, half = lane >> 5;
+  const int nslices = p.ctiles;
+  const int nblocks = nslices * TN;
 
-  // ---- DMA sources.  Halo row hr = lrow + 32 i -> input pixel (y0 - 1 + hr / 34, x0 - 1 + hr % 34).
+  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+  // filter row n = lrow (+ 32 per pass): the 9 taps of one channel slice are contiguous (9 x 128 B)
+  const unsigned wbase = (unsigned)((lrow * p.wrow) * 4 + csrc * 16);
+
+  // ---- fragment addressing (per lane, tile independent)
+  // halo rows read by this lane: hr = (2 w + d) * 34 + xl + kw, d = i + kh in 0..3, kw in 0..2.  aaddr[d][kw] is
+  // the LDS address (stage 0) of chunk (half ^ swz(hr)); the chunks (2 + half), (4 + half), (6 + half) ^ swz(hr)
+  // are that address ^ 0x20 / 0x40 / 0x60 (rows are 128-byte aligned, the chunk index lives in bits 4-6).
+  unsigned aaddr[4][3];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int hr = (2 * wave_u + d) * HW_ + xl + kw;
+      aaddr[d][kw] = lds0 + (unsigned)(hr * ROWB + ((half ^ swz(hr)) << 4));
+    }
+  // filter fragments: row xl of tap t at B_OFF + buf * B_BYTES + t * 4096 + xl * 128, chunk c ^ swz(xl)
+  const unsigned baddr0 = lds0 + (unsigned)(B_OFF + xl * ROWB + ((half ^ swz(xl)) << 4));
+
+  f16x8 fah[2][2], fal[2][2], fbh[2], fbl[2];   // [tile | k-half][k-half]: ONE set, refilled half by half (see tap_step)
+
+  // ---- per-tile state
   unsigned abase[A_LD];
+  int hyx[A_LD];                                       // halo row lrow + 32 i -> (hy << 8 | hx), or -1 past the patch
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
     const int hr = lrow + 32 * i;
     const int hy = hr / HW_, hx = hr - hy * HW_;
-    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-    const bool ok = hr < (TH + 2) * HW_ && (unsigned)y < (unsigned)p.in_h && (unsigned)x < (unsigned)p.in_w;
-    abase[i] = ok ? ((unsigned)((ni * p.in_h + y) * p.in_w + x) * (unsigned)p.in_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
+    hyx[i] = hr < (TH + 2) * HW_ ? (hy << 8 | hx) : -1;
   }
-  // filter row n = lrow: its 9 taps of one channel slice are contiguous (9 x 128 B)
-  const unsigned wbase = (unsigned)((lrow * p.wrow) * 4 + csrc * 16);
-  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
-
-  auto dma_slice = [&](int cs, int stage) {
-    char* a = lds + stage * STAGE_B + wave_u * 8 * ROWB;
+  int ni = 0, y0 = 0, x0 = 0;
+  auto tile_setup = [&](int tile) {
+    const int tx = tile % tiles_x;
+    const int ty = (tile / tiles_x) % tiles_y;
+    ni = tile / (tiles_x * tiles_y);
+    y0 = ty * TH; x0 = tx * TW;
+    // halo row (hy, hx) -> input pixel (y0 - 1 + hy, x0 - 1 + hx)
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int y = y0 - 1 + (hyx[i] >> 8), x = x0 - 1 + (hyx[i] & 255);
+      const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)p.in_h && (unsigned)x < (unsigned)p.in_w;
+      abase[i] = ok ? ((unsigned)((ni * p.in_h + y) * p.in_w + x) * (unsigned)p.in_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
+    }
+  };
+  auto dma_halo = [&](int cs, int stage) {             // 11 (waves 0..2) / 10 (wave 3) instructions
+    char* a = lds + stage * A_BYTES + wave_u * 8 * ROWB;
 #pragma unroll
     for (int i = 0; i < A_LD - 1; ++i) {
       const unsigned ro = abase[i];
@@ -87,172 +149,236 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * (A_LD - 1) * ROWB), 16,
                                                (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(cs * 128)), 0, 0, 0);
     }
-    char* b = lds + stage * STAGE_B + A_BYTES + wave_u * 8 * ROWB;
+  };
+  auto dma_filter = [&](int blk, int buf) {            // block = slice * TN + pass; 9 instructions
+    const int cs = blk / TN, pass = blk - cs * TN;
+    char* b = lds + B_OFF + buf * B_BYTES + wave_u * 8 * ROWB;
+    const unsigned wo = wbase + (unsigned)(pass * 32 * p.wrow * 4 + cs * 9 * 128);
 #pragma unroll
     for (int t = 0; t < 9; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 32 * t * ROWB), 16,
-                                               (int)(wbase + (unsigned)((cs * 9 + t) * 128)), 0, 0, 0);
+                                               (int)(wo + (unsigned)(t * 128)), 0, 0, 0);
   };
 
-  f32x16 acc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-  // ---- fragment addressing
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-  const int xl = lane & 31, half = lane >> 5;
-  const int rb0 = (2 * wave_u) * HW_ + xl;            // halo row of (image row 2w, column xl) at tap (0,0)
-  const int bsw = swz(xl);
-  unsigned boff[4];                                   // filter fragment offsets inside a tap: [hi s0, hi s1, lo s0, lo s1]
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    boff[s] = (unsigned)(xl * ROWB + (((2 * s + half) ^ bsw) << 4));
-    boff[2 + s] = (unsigned)(xl * ROWB + (((4 + 2 * s + half) ^ bsw) << 4));
-  }
-
-  f16x8 fah[2][2][2], fal[2][2][2], fbh[2][2], fbl[2][2];   // [set][tile | k-half][k-half]
-  auto read_frags = [&](auto set_c, int tap, unsigned stage_off) {
-    constexpr int set = decltype(set_c)::value;
-    const int kh = tap / 3, kw = tap - kh * 3;
-    const unsigned sbase = lds0 + stage_off;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int hr = rb0 + (i + kh) * HW_ + kw;
-      const int sw = swz(hr);
-      const unsigned ra = sbase + (unsigned)(hr * ROWB);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        fah[set][i][s] = lds_read128v(ra + (unsigned)(((2 * s + half) ^ sw) << 4));
-        fal[set][i][s] = lds_read128v(ra + (unsigned)(((4 + 2 * s + half) ^ sw) << 4));
-      }
-    }
-    const unsigned rbq = sbase + (unsigned)(A_BYTES + tap * 32 * ROWB);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      fbh[set][s] = lds_read128v(rbq + boff[s]);
-      fbl[set][s] = lds_read128v(rbq + boff[2 + s]);
+  // fragment `idx` (0..11, in the order the MFMAs consume them: k-half 0 {bh, al0, al1, bl, ah0, ah1}, then k-half 1) of
+  // tap TAP from halo stage offset `aoff` / filter buffer offset `boff`
+  auto read_one = [&](auto tap_c, auto idx_c, unsigned aoff, unsigned boff) {
+    constexpr int tap = decltype(tap_c)::value, idx = decltype(idx_c)::value;
+    constexpr int kh = tap / 3, kw = tap % 3;
+    constexpr int s = idx / 6, r = idx % 6;
+    if constexpr (r == 0) fbh[s] = lds_read128i<tap * 4096>((baddr0 + boff) ^ (unsigned)(s ? 0x20 : 0));
+    else if constexpr (r == 3) fbl[s] = lds_read128i<tap * 4096>((baddr0 + boff) ^ (unsigned)(s ? 0x60 : 0x40));
+    else {
+      constexpr int i = (r == 1 || r == 4) ? 0 : 1;
+      constexpr bool lo = r < 3;
+      const unsigned a = (aaddr[i + kh][kw] + aoff) ^ (unsigned)((lo ? 0x40 : 0) | (s ? 0x20 : 0));
+      if constexpr (lo) fal[i][s] = lds_read128i<0>(a);
+      else fah[i][s] = lds_read128i<0>(a);
     }
   };
-  auto mfmas = [&](auto set_c) {
-    constexpr int set = decltype(set_c)::value;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[set][i][s], fbh[set][s], acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][i][s], fbl[set][s], acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][i][s], fbh[set][s], acc[i], 0, 0, 0);
-    }
-  };
-  constexpr std::integral_constant<int, 0> SET0{};
-  constexpr std::integral_constant<int, 1> SET1{};
 
-  // ---- prologue
-  const int nslices = p.ctiles;
-  dma_slice(0, 0);
-  if (nslices > 1) {
-    dma_slice(1, 1);
-    // slice 1 is 19 (wave 3) or 20 (waves 0..2) operations: at most 19 outstanding => slice 0 has landed
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + 9 - 1) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  read_frags(SET0, 0, 0u);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- main loop over (slice, tap), two steps per iteration so the fragment set is a compile-time index
-  int cs = 0, tap = 0;
-  unsigned soff = 0u;                                   // byte offset of the stage holding slice cs
-  const int total = nslices * 9;
-  auto step = [&](auto set_c, auto nset_c, int g) {
-    // prefetch the fragments of step g+1 into the other set, then run step g's MFMAs
-    const bool more = g + 1 < total;
-    if (more) {
-      if (tap == 8) {
-        // next step starts slice cs+1: its stage must have landed for everyone; this slice's stage is
-        // dead afterwards (tap 8's fragments are already in registers), so slice cs+2 may overwrite it
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned noff = soff ? 0u : (unsigned)STAGE_B;
-        read_frags(nset_c, 0, noff);
-        if (cs + 2 < nslices) dma_slice(cs + 2, cs & 1);
-      } else {
-        read_frags(nset_c, tap + 1, soff);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(set_c);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (++tap == 9) { tap = 0; ++cs; soff = soff ? 0u : (unsigned)STAGE_B; }
-  };
-  for (int g = 0; g < total; g += 2) {
-    step(SET0, SET1, g);
-    if (g + 1 < total) step(SET1, SET0, g + 1);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  // ---- epilogue through a [256 pixels][32 channels] fp32 LDS tile
-  float* Cs = smem;
+  // epilogue constants of this thread's 8 channels per pass; output through a buffer resource (out-of-range
+  // pixels get offset 0xFFFFFFFF: the hardware drops the store, no divergent branch around it)
+  float bias8[TN][8], ws8[TN][8];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int row = (2 * wave_u + i) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-      Cs[row * 32 + xl] = acc[i][rr];
-    }
-  __syncthreads();
-  const int ccol = (tid & 3) * 8;
-  if (ccol >= p.cout) return;
-  float bias8[8], ws8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bias8[e] = p.bias != nullptr ? p.bias[ccol + e] : 0.f;
-    ws8[e] = p.wscale[ccol + e];
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int row = (tid >> 2) + 64 * g;
-    const int y = y0 + (row >> 5), x = x0 + (row & 31);
-    if (y >= p.out_h || x >= p.out_w) continue;
-    const long m = ((long)ni * p.out_h + y) * p.out_w + x;
-    float v[8], r1[8], r2[8];
-    {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * 32 + ccol);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * 32 + ccol + 4);
-      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-    }
-    if (p.res1 != nullptr) load8(p.res1, m, p.res1_ld, ccol, p.res1_fmt, r1);
-    if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, ccol, p.res2_fmt, r2);
+  for (int n = 0; n < TN; ++n)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float t = v[e] * ws8[e] + bias8[e];
-      if (p.res1 != nullptr && p.res1_pre) t += r1[e];
-      t = t >= 0.f ? t : t * p.act_slope;
-      t = t * p.alpha;
-      if (p.res1 != nullptr && !p.res1_pre) t += r1[e];
-      if (p.res2 != nullptr) t = t * p.alpha2 + r2[e];
-      v[e] = t;
+      const int c = n * 32 + (tid & 3) * 8 + e;
+      bias8[n][e] = (p.bias != nullptr && c < p.cout) ? p.bias[c] : 0.f;
+      ws8[n][e] = c < p.cout ? p.wscale[c] : 0.f;
     }
-    if (p.out_fmt == 1) {
-      u32x4_t hi, lo;
-      split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
-      char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + split_chan_off(ccol);
-      *reinterpret_cast<u32x4_t*>(ob) = hi;
-      *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
+  __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.in2_bytes, 0x00020000);   // in2_bytes: size of `out` (halo launches)
+
+  // ---- the workgroup's tiles form ONE stream of blocks: a block's filter buffer is refilled two blocks ahead and a
+  //      slice's halo stage two slices ahead ACROSS tile boundaries, so a new tile starts with its operands in LDS
+  //      (no start-of-tile burst in which all 256 workgroups ask HBM for 160 KiB at once and wait for it).
+  int it = slot;
+  if (it >= per_x || xcd * per_x + it >= ntiles) return;
+  tile_setup(xcd * per_x + it);
+  int e_ni = ni, e_y0 = y0, e_x0 = x0;                 // coordinates of the tile being computed (tile_setup runs ahead)
+  dma_halo(0, 0);
+  dma_filter(0, 0);
+  dma_halo(1, 1);                                       // nslices >= 2 (launcher)
+  dma_filter(1, 1);
+  if (wave_u < 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + 9) : "memory");       // halo(1) [11 | 10 per wave] + filter(1) [9] may fly
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD - 1 + 9) : "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x16 acc[TN][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][i][e] = 0.f;
+  };
+  zero_acc();
+
+  // fragments of (block 0, tap 0)
+  static_for<0, 12>([&](auto ic) { read_one(std::integral_constant<int, 0>{}, ic, 0u, 0u); });
+
+  // One tap = 12 MFMAs: six on the k-half-0 fragments, six on the k-half-1 fragments.  There is ONE fragment set: as soon
+  // as the six MFMAs of a k-half have been issued its registers are refilled with the NEXT tap's fragments of that
+  // k-half (the matrix pipe reads its A / B operands when the instruction issues; the LDS data lands tens of cycles
+  // later), which then have six MFMAs (~190 cycles) to arrive.  lgkmcnt(6): the older group of six reads is complete.
+  auto tap_step = [&](auto tap_c, auto pass_c, unsigned aoff_n, unsigned boff_n, bool prefetch) {
+    constexpr int tap = decltype(tap_c)::value, pass = decltype(pass_c)::value;
+    constexpr int ntap = (tap + 1) % 9;
+    static_for<0, 2>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (s == 0 || prefetch) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[pass][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i][s], fbh[s], acc[pass][i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[pass][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i][s], fbl[s], acc[pass][i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[pass][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i][s], fbh[s], acc[pass][i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (prefetch)
+        static_for<0, 6>([&](auto rc) {
+          read_one(std::integral_constant<int, ntap>{}, std::integral_constant<int, 6 * s + decltype(rc)::value>{}, aoff_n, boff_n);
+        });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // epilogue of the finished tile through a [256 pixels][32 channels] fp32 tile in halo stage `stage` (just freed)
+  auto epilogue = [&](int stage) {
+    const unsigned cs0 = lds0 + (unsigned)(stage * A_BYTES);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int row = (2 * wave_u + i) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+          lds_write32(cs0 + (unsigned)((row * 32 + xl) * 4), acc[n][i][rr]);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const int ccol = n * 32 + (tid & 3) * 8;
+      const bool cvalid = ccol < p.cout;
+      f32x4 va[4], vb[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned ra = cs0 + (unsigned)((((tid >> 2) + 64 * g) * 32 + (tid & 3) * 8) * 4);
+        va[g] = lds_read128f(ra);
+        vb[g] = lds_read128f(ra + 16);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = (tid >> 2) + 64 * g;
+        const int y = e_y0 + (row >> 5), x = e_x0 + (row & 31);
+        const bool ok = cvalid && y < p.out_h && x < p.out_w;
+        const long m = ok ? ((long)e_ni * p.out_h + y) * p.out_w + x : 0;
+        float v[8] = {va[g][0], va[g][1], va[g][2], va[g][3], vb[g][0], vb[g][1], vb[g][2], vb[g][3]};
+        float r1[8], r2[8];
+        if (p.res1 != nullptr) load8(p.res1, m, p.res1_ld, cvalid ? ccol : 0, p.res1_fmt, r1);
+        if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, cvalid ? ccol : 0, p.res2_fmt, r2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = v[e] * ws8[n][e] + bias8[n][e];
+          if (p.res1 != nullptr && p.res1_pre) t += r1[e];
+          t = t >= 0.f ? t : t * p.act_slope;
+          t = t * p.alpha;
+          if (p.res1 != nullptr && !p.res1_pre) t += r1[e];
+          if (p.res2 != nullptr) t = t * p.alpha2 + r2[e];
+          v[e] = t;
+        }
+        u32x4_t s0, s1;
+        unsigned o0, o1;
+        if (p.out_fmt == 1) {
+          split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, s0, s1);
+          o0 = (unsigned)(m * p.out_ld * 4 + split_chan_off(ccol));
+          o1 = o0 + 64u;
+        } else {
+          s0 = __builtin_bit_cast(u32x4_t, f32x4{v[0], v[1], v[2], v[3]});
+          s1 = __builtin_bit_cast(u32x4_t, f32x4{v[4], v[5], v[6], v[7]});
+          o0 = (unsigned)((m * p.out_ld + ccol) * 4);
+          o1 = o0 + 16u;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(s0, rs_out, ok ? o0 : 0xFFFFFFFFu, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(s1, rs_out, ok ? o1 : 0xFFFFFFFFu, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                                 // the fp32 tile may be rewritten / its stage refilled
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- main loop over the stream of blocks (slice, pass): nine unrolled taps each
+  int blk = 0;                                          // block index inside the current tile
+  unsigned bbuf = 0, astage = 0;                        // filter buffer of the current block, halo stage of the current slice
+  auto run_block = [&](auto pass_c) -> bool {           // true: the workgroup is done
+    constexpr int pass = decltype(pass_c)::value;
+    constexpr bool new_slice = pass == TN - 1;                       // the next block starts the next channel slice
+    const int cs = blk / TN;
+    const unsigned aoff = astage * (unsigned)A_BYTES, boff = bbuf * (unsigned)B_BYTES;
+    const bool last_of_tile = blk == nblocks - 1;
+    const int nit = it + slots, ntile = xcd * per_x + nit;
+    const bool more = nit < per_x && ntile < ntiles;
+    static_for<0, 8>([&](auto tc) { tap_step(tc, pass_c, aoff, boff, true); });
+    // tap 8's fragments are (about to be) in registers: the block's buffer (and, after the last pass, the slice's
+    // stage) is dead for this wave; the next block's operands were requested a block ago
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // refill what just died with the operands of the block two ahead in the stream
+    bool halo_delayed = false;
+    {
+      const int b2 = blk + 2;
+      if (b2 < nblocks) dma_filter(b2, (int)bbuf);
+      else if (more) dma_filter(b2 - nblocks, (int)bbuf);
+      if constexpr (new_slice) {
+        const int s2 = cs + 2;
+        if (s2 < nslices) dma_halo(s2, (int)astage);
+        else if (more) {
+          if (s2 == nslices) {                                       // next tile's first slice: its addresses replace this tile's
+            tile_setup(ntile);
+            dma_halo(0, (int)astage);
+          } else {
+            halo_delayed = true;                                     // next tile's second slice: the freed stage hosts the epilogue first
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned aoff_next = new_slice ? (astage ^ 1u) * (unsigned)A_BYTES : aoff;
+    const unsigned boff_next = (bbuf ^ 1u) * (unsigned)B_BYTES;
+    tap_step(std::integral_constant<int, 8>{}, pass_c, aoff_next, boff_next, !(last_of_tile && !more));
+    const unsigned freed = astage;
+    bbuf ^= 1u;
+    if constexpr (new_slice) astage ^= 1u;
+    ++blk;
+    if constexpr (new_slice) {
+      if (last_of_tile) {
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue((int)freed);
+        if (!more) return true;
+        if (halo_delayed) dma_halo(1, (int)freed);
+        it = nit;
+        blk = 0;
+        e_ni = ni; e_y0 = y0; e_x0 = x0;
+        zero_acc();
+      }
+    }
+    return false;
+  };
+  for (;;) {
+    if constexpr (TN == 2) {
+      if (run_block(std::integral_constant<int, 0>{})) break;
+      if (run_block(std::integral_constant<int, 1>{})) break;
     } else {
-      float* dst = p.out + m * p.out_ld + ccol;
-      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      if (run_block(std::integral_constant<int, 0>{})) break;
     }
   }
 }
@@ -262,11 +388,25 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
 namespace fcp_conv {
 
 int launch_f16x3_halo(const ConvK& k, hipStream_t s) {
-  const size_t lds = 2 * (size_t)STAGE_B;
-  FCP_LDS_OPT_IN(&conv3x3_halo_f16x3, lds);
+  const size_t lds = (size_t)LDS_TOTAL;
   const long tiles = (long)k.n * ((k.out_h + TH - 1) / TH) * ((k.out_w + TW - 1) / TW);
   FCP_REQUIRE(tiles < (1L << 31), "conv(halo): too many tiles");
-  hipLaunchKernelGGL(conv3x3_halo_f16x3, dim3((unsigned)tiles), dim3(256), lds, s, k);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    FCP_HIP_OK(hipGetDevice(&dev));
+    FCP_HIP_OK(hipGetDeviceProperties(&prop, dev));
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
+  if (k.cout <= 32) {
+    FCP_LDS_OPT_IN(&conv3x3_halo_f16x3<1>, lds);
+    hipLaunchKernelGGL(conv3x3_halo_f16x3<1>, dim3(grid), dim3(256), lds, s, k);
+  } else {
+    FCP_LDS_OPT_IN(&conv3x3_halo_f16x3<2>, lds);
+    hipLaunchKernelGGL(conv3x3_halo_f16x3<2>, dim3(grid), dim3(256), lds, s, k);
+  }
   FCP_LAUNCH_OK();
   return 0;
 }

@@ -302,18 +302,29 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     big_ok = (pc.precision == 1 and x.fmt == 1 and not pc.cin4 and not in_up2 and pc.cout % 8 == 0
               and pc.cout >= 128 and m >= 256 * 64)
     halo_ok = (pc.precision == 1 and x.fmt == 1 and not pc.cin4 and not in_up2 and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1)
-               and pc.cout <= 32 and pc.cout % 8 == 0 and x2 is None and (res1 is None or (res1.h, res1.w) == (oh, ow)))
+               and pc.cout <= 64 and pc.cout % 8 == 0 and pc.cin >= 64 and x2 is None and (res1 is None or (res1.h, res1.w) == (oh, ow)))
     if tile_n is None and tile_m is None and (pc.cout > 64 or halo_ok) and (Autotune.enabled or Autotune.cache):
         key = (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, m, int(in_up2), res1 is not None, res2 is not None,
                pc.precision, x.fmt, out.fmt, None if x2 is None else (x2.c, x2_stride))
         best = Autotune.cache.get(key)          # a tuned shape keeps its tile after tuning is switched off
         if best is None and Autotune.enabled:
+            # Tuning launches the op several times.  An op whose output aliases one of its inputs (RRDB's last dense-block
+            # conv writes the buffer its second residual is read from) is not idempotent: its trial launches write a
+            # scratch tensor of the same geometry instead, and only the final launch below touches the real output.
+            real_out = d.out
+            aliased = any(t is not None and t.buf.untyped_storage().data_ptr() == out.buf.untyped_storage().data_ptr()
+                          for t in (x, x2, res1, res2))
+            scratch = torch.empty_like(out.buf) if aliased else None
+
             def _launch(t):
                 d.tile_m, d.tile_n = t
+                if scratch is not None:
+                    d.out = N.ptr(scratch, 4 * out.c0)
                 N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
+                d.out = real_out
             cands = [(128, 64), (128, 128)]
             if halo_ok:
-                cands = [(128, 32), (128, 64), (1, 32)]
+                cands = ([(128, 32)] if pc.cout <= 32 else []) + [(128, 64), (1, 32)]
             if big_ok and BIG_TILES:
                 cands += [(256, 128)] + ([(256, 256)] if pc.cout >= 256 else [])
             best = Autotune.pick(key, cands, _launch)

@@ -282,11 +282,14 @@ def test_conv_two_sources(c1, c2, cout, stride, hw, device, precision):
         E.conv(pc3, xa, x2=xb, x2_stride=stride)
 
 
-@pytest.mark.parametrize("cin,cout,hw,n", [(64, 32, (16, 64), 2), (96, 32, (19, 45), 1), (160, 24, (8, 32), 3), (32, 32, (5, 7), 2),
-                                           (192, 8, (33, 70), 1)])
+@pytest.mark.parametrize("cin,cout,hw,n", [(64, 32, (16, 64), 2), (96, 32, (19, 45), 1), (160, 24, (8, 32), 3), (64, 32, (5, 7), 2),
+                                           (192, 8, (33, 70), 1), (192, 64, (40, 70), 2), (64, 64, (9, 33), 1), (96, 40, (17, 20), 2),
+                                           (96, 32, (256, 384), 3), (128, 64, (200, 300), 2)])
 def test_conv_halo_tiles(cin, cout, hw, n, device, precision):
-    """The halo-tile 3x3 kernel (tile_m=1, RRDB's 32-filter convs): bit-identical to the implicit-GEMM kernel;
-    ragged patches (H % 8, W % 32 != 0), image borders, odd slice counts, residual + LeakyReLU epilogue."""
+    """The halo-tile 3x3 kernel (tile_m=1; RRDB's 32- and 64-filter convs): bit-identical to the implicit-GEMM
+    kernel; ragged patches (H % 8, W % 32 != 0), image borders, odd and even slice counts, one and two filter passes,
+    residual + LeakyReLU epilogue, and images with more patches than CUs (the persistent tile loop, where the next
+    tile's first DMA overlaps the epilogue)."""
     if precision != "f16x3":
         pytest.skip("split32 tensors exist only on the fp16x3 path")
     from face_crop_plus_amd import engine as E
@@ -300,19 +303,26 @@ def test_conv_halo_tiles(cin, cout, hw, n, device, precision):
     pc = E.pack_conv(wt, b, None, 1, 1, device)
     xs = E.f32_to_split32(E.Act(_nhwc(x, device)))
     rs = E.Act(_nhwc(res, device))
-    base = E.conv(pc, xs, act_slope=0.2, alpha=0.5, res1=rs, res1_pre=False, tile_m=128, tile_n=32)
+    tn = 32 if cout <= 32 else 64
+    base = E.conv(pc, xs, act_slope=0.2, alpha=0.5, res1=rs, res1_pre=False, tile_m=128, tile_n=tn)
     assert (base.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
     out = E.conv(pc, xs, act_slope=0.2, alpha=0.5, res1=rs, res1_pre=False, tile_m=1, tile_n=32)
     assert torch.equal(out.buf, base.buf)
+    again = E.conv(pc, xs, act_slope=0.2, alpha=0.5, res1=rs, res1_pre=False, tile_m=1, tile_n=32)
+    assert torch.equal(again.buf, out.buf)                         # no race between a tile's epilogue and the next tile's DMA
     if cout % 32 == 0:                                             # dense-block style: write a slice of a wider split32 buffer
-        wide = E.Act.empty(n, h, w, 96, device, 1)
+        wide = E.Act.empty(n, h, w, 64 + cout, device, 1)
         wide.buf.zero_()
-        E.conv(pc, xs, wide.slice(64, 32), act_slope=0.2, tile_m=1, tile_n=32)
+        E.conv(pc, xs, wide.slice(64, cout), act_slope=0.2, tile_m=1, tile_n=32)
         ref2 = F.leaky_relu(F.conv2d(x, wt, b, 1, 1), 0.2)
         got = wide.nchw().cpu()
         assert (got[:, 64:] - ref2).abs().max().item() <= _tol(ref2) and got[:, :64].abs().max().item() == 0
+        rs2 = E.f32_to_split32(E.Act(_nhwc(torch.randn(n, cout, h, w, generator=g), device)))   # conv5-style double residual
+        a5 = E.conv(pc, xs, alpha=0.2, res1=rs, res1_pre=False, res2=rs2, alpha2=0.2, out_fmt=1, tile_m=128, tile_n=tn)
+        b5 = E.conv(pc, xs, alpha=0.2, res1=rs, res1_pre=False, res2=rs2, alpha2=0.2, out_fmt=1, tile_m=1, tile_n=32)
+        assert torch.equal(a5.buf, b5.buf)
     with pytest.raises(RuntimeError, match="halo-tile"):
-        E.conv(E.pack_conv(torch.randn(64, cin, 3, 3), None, None, 1, 1, device), xs, tile_m=1, tile_n=64)
+        E.conv(E.pack_conv(torch.randn(96, cin, 3, 3), None, None, 1, 1, device), xs, tile_m=1, tile_n=64)
 
 
 @pytest.mark.parametrize("n,h,w", [(2, 77, 91), (1, 64, 64), (3, 50, 130), (1, 9, 200), (2, 640, 640)])
@@ -440,3 +450,28 @@ def test_conv_flat_flag_rejected_on_f16x3(device):
     pc = E.pack_conv(wt, None, None, 1, 0, device, precision="f16x3")
     with pytest.raises(RuntimeError, match="FCP_CONV_FLAT_ADDR"):
         E.conv(pc, E.Act(torch.zeros(1, 4, 4, 64, device=device)), flat=True)
+
+
+def test_autotune_does_not_corrupt_in_place_ops(device, precision):
+    """An op whose output aliases a residual (RRDB conv5 of the third dense block: out and res2 are the same
+    tensor) must give the same result whether or not its shape is being autotuned (trial launches go to scratch)."""
+    if precision != "f16x3":
+        pytest.skip("autotuned tiles exist on the fp16x3 path")
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(9)
+    n, h, w = 1, 24, 40
+    wt = torch.randn(64, 192, 3, 3, generator=g) / 42
+    pc = E.pack_conv(wt, torch.randn(64, generator=g), None, 1, 1, device)
+    src = E.f32_to_split32(E.Act(torch.randn(n, h, w, 192, generator=g).to(device)))
+    base = torch.randn(n, h, w, 192, generator=g).to(device)
+    outs = []
+    for tuned in (False, True):
+        tgt = E.f32_to_split32(E.Act(base.clone()))
+        prev, E.Autotune.enabled = E.Autotune.enabled, tuned
+        saved, E.Autotune.cache = E.Autotune.cache, {}
+        try:
+            E.conv(pc, src, tgt.slice(0, 64), alpha=0.2, res1=src.slice(0, 64), res1_pre=False, res2=tgt.slice(0, 64), alpha2=0.2)
+        finally:
+            E.Autotune.enabled, E.Autotune.cache = prev, saved
+        outs.append(tgt.buf.clone())
+    assert torch.equal(outs[0], outs[1])
