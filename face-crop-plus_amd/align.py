@@ -6,6 +6,7 @@ import numpy as np
 import torch
 
 from . import _native as N
+from . import torch_ops as T
 
 BORDER_MODES = {"constant": 0, "replicate": 1, "reflect": 2, "wrap": 3, "reflect_101": 4,
                 "reflect101": 4, "default": 4}
@@ -31,6 +32,9 @@ def estimate_transform(landmarks: torch.Tensor, target: torch.Tensor, allow_skew
     """landmarks (F,k,2) f32 device, target (k,2) f32 device -> (mat (F,6) f64, ok (F,) i32)."""
     f, k = landmarks.shape[0], landmarks.shape[1]
     dev = landmarks.device
+    if T.ENABLED:
+        mat, ok = T.load().similarity_from_5pt(landmarks.contiguous(), target.contiguous(), bool(allow_skew))
+        return mat.view(f, 6), ok
     mat = torch.empty((f, 6), dtype=torch.float64, device=dev)
     ok = torch.empty((f,), dtype=torch.int32, device=dev)
     N.check(N.lib().fcp_estimate_transform(N.ptr(landmarks.contiguous()), N.ptr(target.contiguous()), f, k,
@@ -46,6 +50,8 @@ def warp_affine(images_u8: torch.Tensor, img_idx: torch.Tensor, mat: torch.Tenso
     n, h, w, _ = images_u8.shape
     f = img_idx.shape[0]
     ow, oh = int(output_size[0]), int(output_size[1])
+    if T.ENABLED:
+        return T.load().warp_affine_u8(images_u8, img_idx, mat.contiguous().view(f, 2, 3), ok, paddings, ow, oh, int(border))
     out = torch.empty((f, oh, ow, 3), dtype=torch.uint8, device=images_u8.device)
     N.check(N.lib().fcp_warp_affine_u8(N.ptr(images_u8), n, h, w, N.ptr(img_idx), N.ptr(mat), N.ptr(ok),
                                        N.ptr(paddings), f, oh, ow, int(border), N.ptr(out), N.stream_ptr()),

@@ -66,7 +66,32 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_torch_ops(force, verbose)
     return LIB
+
+
+TORCH_LIB = os.path.join(CSRC, "libfcp_torch.so")
+TORCH_SRC = os.path.join(CSRC, "torch_ops", "fcp_torch_ops.cpp")
+
+
+def build_torch_ops(force: bool = False, verbose: bool = True) -> str:
+    """csrc/torch_ops/fcp_torch_ops.cpp -> csrc/libfcp_torch.so: the TORCH_LIBRARY(fcp) registration of the ops over the
+    C ABI (host C++ only: g++ against the installed torch headers / libraries, linked to libfcp_hip.so via $ORIGIN)."""
+    headers = [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    if not force and _newer(TORCH_LIB, [TORCH_SRC, LIB] + headers):
+        return TORCH_LIB
+    import torch
+    tl = os.path.dirname(torch.__file__)
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={abi}", f"-I{tl}/include", f"-I{tl}/include/torch/csrc/api/include", f"-I{rocm}/include",
+           f"-I{INCLUDE}", TORCH_SRC, "-o", TORCH_LIB, f"-L{tl}/lib", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip",
+           f"-L{CSRC}", "-lfcp_hip", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tl}/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TORCH_LIB
 
 
 if __name__ == "__main__":

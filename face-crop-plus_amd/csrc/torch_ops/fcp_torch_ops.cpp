@@ -1,0 +1,235 @@
+// PyTorch-ROCm custom ops over the C ABI of include/fcp_hip.h ("a PyTorch-ROCm extension, TORCH_LIBRARY
+// namespace ... stateless ops on the current HIP stream, tensors in/out, no hidden global state").
+//
+//     torch.ops.fcp.conv2d / bottleneck_chain / retina_decode / nms_select / gather_faces / similarity_from_5pt /
+//     warp_affine_u8 / bicubic_down4_round / parse_argmax_hist
+//
+// Each op validates device / dtype / contiguity with TORCH_CHECK (-> RuntimeError), allocates its outputs with torch's
+// caching allocator, borrows its inputs, enqueues the HIP kernels of libfcp_hip.so on at::hip's CURRENT stream and
+// returns without synchronising: the ops are stream-ordered and safe to capture in a HIP graph.  Schemas are plain
+// (Tensor / int / float / bool), so torch.library can attach fake-tensor implementations for torch.compile.
+// The ops are a veneer: all arithmetic lives behind the C ABI, which stays the drop-in boundary.
+#include <ATen/ATen.h>
+#include <ATen/hip/HIPContext.h>
+#include <torch/library.h>
+
+#include <tuple>
+
+#include "fcp_hip.h"
+
+namespace {
+
+using at::Tensor;
+
+void* cur_stream() { return (void*)at::hip::getCurrentHIPStream().stream(); }
+
+void ok(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed (", rc, "): ", fcp_last_error()); }
+
+const Tensor& dev(const Tensor& t, const char* name, at::ScalarType dt) {
+  TORCH_CHECK(t.is_cuda(), name, " must live on the GPU");
+  TORCH_CHECK(t.scalar_type() == dt, name, " has dtype ", t.scalar_type(), ", expected ", dt);
+  TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
+  return t;
+}
+template <typename T>
+const T* optp(const c10::optional<Tensor>& t, const char* name, at::ScalarType dt) {
+  if (!t.has_value() || !t->defined()) return nullptr;
+  return dev(*t, name, dt).data_ptr<T>();
+}
+
+// ---- conv engine.  x / res1 / res2 / out are NHWC buffers (n, h, w, ld); *_c0 selects the first channel of the view.
+// `out` (optional) lets the caller write a channel slice of a wider buffer (torch.cat without a copy); otherwise a
+// dense (n, oh, ow, cout) tensor is allocated.
+Tensor conv2d(const Tensor& x, int64_t x_c0, int64_t cin, const Tensor& w, const c10::optional<Tensor>& bias,
+              const c10::optional<Tensor>& wscale, const c10::optional<Tensor>& res1, int64_t res1_c0,
+              const c10::optional<Tensor>& res2, int64_t res2_c0, const c10::optional<Tensor>& out_, int64_t out_c0,
+              int64_t cout, int64_t kh, int64_t kw, int64_t stride, int64_t pad, double act_slope, double alpha,
+              double alpha2, bool res1_pre, int64_t precision, int64_t in_fmt, int64_t out_fmt, int64_t res1_fmt,
+              int64_t res2_fmt, bool in_up2, bool cin4, int64_t tile_m, int64_t tile_n, const c10::optional<Tensor>& x2,
+              int64_t x2_c0, int64_t cin2, int64_t x2_stride, int64_t flags) {
+  dev(x, "x", at::kFloat);
+  TORCH_CHECK(x.dim() == 4, "x must be NHWC (n, h, w, ld)");
+  TORCH_CHECK(w.is_cuda() && w.is_contiguous(), "w must be a contiguous GPU tensor (packed filter)");
+  const int64_t n = x.size(0), ph = x.size(1), pw = x.size(2), ld = x.size(3);
+  const int64_t ih = in_up2 ? 2 * ph : ph, iw = in_up2 ? 2 * pw : pw;
+  const int64_t oh = (ih + 2 * pad - kh) / stride + 1, ow = (iw + 2 * pad - kw) / stride + 1;
+  Tensor out = out_.has_value() && out_->defined() ? *out_ : at::empty({n, oh, ow, cout}, x.options());
+  dev(out, "out", at::kFloat);
+  TORCH_CHECK(out.dim() == 4 && out.size(0) == n && out.size(1) == oh && out.size(2) == ow && out_c0 + cout <= out.size(3),
+              "out has the wrong geometry");
+  TORCH_CHECK(x_c0 + (cin4 ? 4 : cin - cin2) <= ld, "input channel view exceeds the buffer");
+  fcp_conv_desc d = {};
+  d.in = x.data_ptr<float>() + x_c0;
+  d.w = w.data_ptr();
+  d.bias = optp<float>(bias, "bias", at::kFloat);
+  d.wscale = optp<float>(wscale, "wscale", at::kFloat);
+  d.out = out.data_ptr<float>() + out_c0;
+  d.n = (int)n; d.in_h = (int)ih; d.in_w = (int)iw; d.cin = (int)cin; d.in_ld = (int)ld; d.in_up2 = in_up2;
+  d.cout = (int)cout; d.kh = (int)kh; d.kw = (int)kw; d.stride = (int)stride; d.pad = (int)pad;
+  d.out_h = (int)oh; d.out_w = (int)ow; d.out_ld = (int)out.size(3);
+  d.tile_n = (int)tile_n; d.tile_m = (int)tile_m; d.cin4 = cin4;
+  d.act_slope = (float)act_slope; d.alpha = (float)alpha; d.alpha2 = (float)alpha2;
+  d.res1_pre = res1_pre; d.precision = (int)precision;
+  d.in_fmt = (int)in_fmt; d.out_fmt = (int)out_fmt; d.res1_fmt = (int)res1_fmt; d.res2_fmt = (int)res2_fmt;
+  if (res1.has_value() && res1->defined()) {
+    dev(*res1, "res1", at::kFloat);
+    d.res1 = res1->data_ptr<float>() + res1_c0;
+    d.res1_ld = (int)res1->size(3); d.res1_h = (int)res1->size(1); d.res1_w = (int)res1->size(2);
+  }
+  if (res2.has_value() && res2->defined()) {
+    dev(*res2, "res2", at::kFloat);
+    d.res2 = res2->data_ptr<float>() + res2_c0;
+    d.res2_ld = (int)res2->size(3);
+  }
+  if (x2.has_value() && x2->defined()) {                 // second source of a 1x1 conv (K concatenation)
+    dev(*x2, "x2", at::kFloat);
+    d.in2 = x2->data_ptr<float>() + x2_c0;
+    d.cin2 = (int)cin2; d.in2_ld = (int)x2->size(3); d.in2_h = (int)x2->size(1); d.in2_w = (int)x2->size(2);
+    d.in2_stride = (int)x2_stride;
+  }
+  d.flags = (int)flags;
+  ok(fcp_conv2d_nhwc_f32(&d, cur_stream()), "fcp::conv2d");
+  return out;
+}
+
+std::tuple<Tensor, Tensor> bottleneck_chain(const Tensor& t1, int64_t t1_c0, const Tensor& res, int64_t res_c0, const Tensor& w2,
+                                            const Tensor& ws2, const Tensor& b2, const Tensor& w3, const Tensor& ws3,
+                                            const Tensor& b3, const Tensor& w1n, const Tensor& ws1n, const Tensor& b1n,
+                                            int64_t cn) {
+  dev(t1, "t1", at::kFloat); dev(res, "res", at::kFloat);
+  TORCH_CHECK(t1.dim() == 4 && res.dim() == 4 && t1_c0 + 64 <= t1.size(3) && res_c0 + 256 <= res.size(3),
+              "t1 (n,h,w,>=64) / res (n,h,w,>=256) split32 buffers");
+  Tensor out = at::empty({t1.size(0), t1.size(1), t1.size(2), 256}, t1.options());
+  Tensor t1n = at::empty({t1.size(0), t1.size(1), t1.size(2), cn}, t1.options());
+  fcp_chain_desc d = {};
+  d.t1 = t1.data_ptr<float>() + t1_c0; d.res = res.data_ptr<float>() + res_c0; d.out = out.data_ptr<float>(); d.t1n = t1n.data_ptr<float>();
+  d.w2 = w2.data_ptr(); d.ws2 = dev(ws2, "ws2", at::kFloat).data_ptr<float>(); d.b2 = dev(b2, "b2", at::kFloat).data_ptr<float>();
+  d.w3 = w3.data_ptr(); d.ws3 = dev(ws3, "ws3", at::kFloat).data_ptr<float>(); d.b3 = dev(b3, "b3", at::kFloat).data_ptr<float>();
+  d.w1n = w1n.data_ptr(); d.ws1n = dev(ws1n, "ws1n", at::kFloat).data_ptr<float>(); d.b1n = dev(b1n, "b1n", at::kFloat).data_ptr<float>();
+  d.n = (int)t1.size(0); d.h = (int)t1.size(1); d.w = (int)t1.size(2); d.c = 64; d.cn = (int)cn;
+  d.t1_ld = (int)t1.size(3); d.res_ld = (int)res.size(3); d.out_ld = 256; d.t1n_ld = (int)cn;
+  ok(fcp_bottleneck_chain_f16x3(&d, cur_stream()), "fcp::bottleneck_chain");
+  return {out, t1n};
+}
+
+// ---- detect_postprocess: three fused head maps -> compacted candidates
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> retina_decode(const Tensor& h0, const Tensor& h1, const Tensor& h2,
+                                                                 int64_t img_h, int64_t img_w, double vis, double var0,
+                                                                 double var1) {
+  dev(h0, "head0", at::kFloat); dev(h1, "head1", at::kFloat); dev(h2, "head2", at::kFloat);
+  const int64_t n = h0.size(0);
+  int64_t P = 0;
+  for (int64_t s : {8, 16, 32}) P += 2 * ((img_h + s - 1) / s) * ((img_w + s - 1) / s);
+  auto f = h0.options();
+  auto i = h0.options().dtype(at::kInt);
+  Tensor score = at::empty({n, P}, f), box = at::empty({n, P, 4}, f), ldm = at::empty({n, P, 10}, f);
+  Tensor prior = at::empty({n, P}, i), count = at::empty({n}, i);
+  ok(fcp_retina_decode(h0.data_ptr<float>(), h1.data_ptr<float>(), h2.data_ptr<float>(), (int)n, (int)img_h, (int)img_w,
+                       (float)vis, (float)var0, (float)var1, score.data_ptr<float>(), box.data_ptr<float>(),
+                       ldm.data_ptr<float>(), prior.data_ptr<int>(), count.data_ptr<int>(), nullptr, nullptr, nullptr,
+                       cur_stream()), "fcp::retina_decode");
+  return {score, box, ldm, prior, count};
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> nms_select(const Tensor& score, const Tensor& box, const Tensor& count,
+                                                      double thr, int64_t strategy) {
+  dev(score, "cand_score", at::kFloat); dev(box, "cand_box", at::kFloat); dev(count, "cand_count", at::kInt);
+  const int64_t n = score.size(0), cap = score.size(1);
+  auto i = score.options().dtype(at::kInt);
+  Tensor ws = at::empty({fcp_retina_nms_workspace_bytes((int)n, (int)cap)}, score.options().dtype(at::kByte));
+  Tensor keep_pos = at::empty({n, cap}, i), keep_count = at::empty({n}, i), sel_pos = at::empty({n, cap}, i), sel_count = at::empty({n}, i);
+  ok(fcp_retina_nms_select(score.data_ptr<float>(), box.data_ptr<float>(), count.data_ptr<int>(), (int)n, (int)cap, (float)thr,
+                           (int)strategy, ws.data_ptr(), keep_pos.data_ptr<int>(), keep_count.data_ptr<int>(),
+                           sel_pos.data_ptr<int>(), sel_count.data_ptr<int>(), cur_stream()), "fcp::nms_select");
+  return {keep_pos, keep_count, sel_pos, sel_count};
+}
+
+std::tuple<Tensor, Tensor, Tensor> gather_faces(const Tensor& ldm, const Tensor& sel_pos, const Tensor& sel_count,
+                                                const c10::optional<Tensor>& paddings, int64_t max_faces) {
+  dev(ldm, "cand_ldm", at::kFloat); dev(sel_pos, "sel_pos", at::kInt); dev(sel_count, "sel_count", at::kInt);
+  const int64_t n = sel_pos.size(0), cap = sel_pos.size(1);
+  auto i = ldm.options().dtype(at::kInt);
+  Tensor off = at::empty({n + 1}, i), out_ldm = at::zeros({max_faces, 5, 2}, ldm.options()), out_img = at::zeros({max_faces}, i);
+  ok(fcp_retina_gather_faces(ldm.data_ptr<float>(), sel_pos.data_ptr<int>(), sel_count.data_ptr<int>(), (int)n, (int)cap,
+                             optp<int>(paddings, "paddings", at::kInt), (int)max_faces, off.data_ptr<int>(),
+                             out_ldm.data_ptr<float>(), out_img.data_ptr<int>(), cur_stream()), "fcp::gather_faces");
+  return {out_ldm, out_img, off};
+}
+
+std::tuple<Tensor, Tensor> similarity_from_5pt(const Tensor& src, const Tensor& dst, bool allow_skew) {
+  dev(src, "src", at::kFloat); dev(dst, "dst", at::kFloat);
+  TORCH_CHECK(src.dim() == 3 && src.size(2) == 2 && dst.dim() == 2 && dst.size(0) == src.size(1), "src (f,k,2), dst (k,2)");
+  const int64_t f = src.size(0);
+  Tensor mat = at::empty({f, 2, 3}, src.options().dtype(at::kDouble)), okf = at::empty({f}, src.options().dtype(at::kInt));
+  ok(fcp_estimate_transform(src.data_ptr<float>(), dst.data_ptr<float>(), (int)f, (int)src.size(1), allow_skew,
+                            mat.data_ptr<double>(), okf.data_ptr<int>(), cur_stream()), "fcp::similarity_from_5pt");
+  return {mat, okf};
+}
+
+Tensor warp_affine_u8(const Tensor& images, const Tensor& img_idx, const Tensor& mat, const c10::optional<Tensor>& okf,
+                      const c10::optional<Tensor>& paddings, int64_t out_w, int64_t out_h, int64_t border) {
+  dev(images, "images", at::kByte); dev(img_idx, "img_idx", at::kInt); dev(mat, "mat", at::kDouble);
+  TORCH_CHECK(images.dim() == 4 && images.size(3) == 3, "images (n,h,w,3) uint8");
+  const int64_t f = img_idx.size(0);
+  Tensor out = at::empty({f, out_h, out_w, 3}, images.options());
+  ok(fcp_warp_affine_u8(images.data_ptr<uint8_t>(), (int)images.size(0), (int)images.size(1), (int)images.size(2),
+                        img_idx.data_ptr<int>(), mat.data_ptr<double>(), optp<int>(okf, "ok", at::kInt),
+                        optp<int>(paddings, "paddings", at::kInt), (int)f, (int)out_h, (int)out_w, (int)border,
+                        out.data_ptr<uint8_t>(), cur_stream()), "fcp::warp_affine_u8");
+  return out;
+}
+
+Tensor bicubic_down4_round(const Tensor& x4) {
+  dev(x4, "x4", at::kFloat);
+  TORCH_CHECK(x4.dim() == 3 && x4.size(0) % 4 == 0 && x4.size(1) % 4 == 0 && x4.size(2) >= 3, "x4 (4h,4w,ld>=3) fp32");
+  const int64_t h = x4.size(0) / 4, w = x4.size(1) / 4;
+  Tensor out = at::empty({h, w, 3}, x4.options().dtype(at::kByte));
+  ok(fcp_bicubic_down4_u8(x4.data_ptr<float>(), (int)h, (int)w, (int)x4.size(2), out.data_ptr<uint8_t>(), cur_stream()),
+     "fcp::bicubic_down4_round");
+  return out;
+}
+
+std::tuple<Tensor, Tensor> parse_argmax_hist(const Tensor& logits, int64_t ncls, int64_t mid_h, int64_t mid_w, int64_t out_h,
+                                             int64_t out_w) {
+  dev(logits, "logits", at::kFloat);
+  TORCH_CHECK(logits.dim() == 4 && logits.size(3) >= ncls, "logits (f,lh,lw,ld>=ncls)");
+  const int64_t f = logits.size(0);
+  Tensor labels = at::empty({f, out_h, out_w}, logits.options().dtype(at::kByte));
+  Tensor counts = at::empty({f, ncls}, logits.options().dtype(at::kInt));
+  ok(fcp_parse_tail(logits.data_ptr<float>(), (int)f, (int)logits.size(1), (int)logits.size(2), (int)logits.size(3), (int)ncls,
+                    (int)mid_h, (int)mid_w, (int)out_h, (int)out_w, labels.data_ptr<uint8_t>(), counts.data_ptr<int>(), cur_stream()),
+     "fcp::parse_argmax_hist");
+  return {labels, counts};
+}
+
+}  // namespace
+
+TORCH_LIBRARY(fcp, m) {
+  m.def("conv2d(Tensor x, int x_c0, int cin, Tensor w, Tensor? bias, Tensor? wscale, Tensor? res1, int res1_c0, Tensor? res2, "
+        "int res2_c0, Tensor(a!)? out, int out_c0, int cout, int kh, int kw, int stride, int pad, float act_slope, float alpha, "
+        "float alpha2, bool res1_pre, int precision, int in_fmt, int out_fmt, int res1_fmt, int res2_fmt, bool in_up2, "
+        "bool cin4, int tile_m, int tile_n, Tensor? x2, int x2_c0, int cin2, int x2_stride, int flags) -> Tensor");
+  m.def("bottleneck_chain(Tensor t1, int t1_c0, Tensor res, int res_c0, Tensor w2, Tensor ws2, Tensor b2, Tensor w3, Tensor ws3, Tensor b3, "
+        "Tensor w1n, Tensor ws1n, Tensor b1n, int cn) -> (Tensor, Tensor)");
+  m.def("retina_decode(Tensor head0, Tensor head1, Tensor head2, int img_h, int img_w, float vis, float var0, float var1) "
+        "-> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+  m.def("nms_select(Tensor cand_score, Tensor cand_box, Tensor cand_count, float nms_threshold, int strategy) "
+        "-> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("gather_faces(Tensor cand_ldm, Tensor sel_pos, Tensor sel_count, Tensor? paddings, int max_faces) -> (Tensor, Tensor, Tensor)");
+  m.def("similarity_from_5pt(Tensor src, Tensor dst, bool allow_skew) -> (Tensor, Tensor)");
+  m.def("warp_affine_u8(Tensor images, Tensor img_idx, Tensor mat, Tensor? ok, Tensor? paddings, int out_w, int out_h, int border) -> Tensor");
+  m.def("bicubic_down4_round(Tensor x4) -> Tensor");
+  m.def("parse_argmax_hist(Tensor logits, int ncls, int mid_h, int mid_w, int out_h, int out_w) -> (Tensor, Tensor)");
+}
+
+TORCH_LIBRARY_IMPL(fcp, CUDA, m) {
+  m.impl("conv2d", &conv2d);
+  m.impl("bottleneck_chain", &bottleneck_chain);
+  m.impl("retina_decode", &retina_decode);
+  m.impl("nms_select", &nms_select);
+  m.impl("gather_faces", &gather_faces);
+  m.impl("similarity_from_5pt", &similarity_from_5pt);
+  m.impl("warp_affine_u8", &warp_affine_u8);
+  m.impl("bicubic_down4_round", &bicubic_down4_round);
+  m.impl("parse_argmax_hist", &parse_argmax_hist);
+}

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _native as N
+from . import torch_ops as T
 
 BN_EPS = 1e-5
 COUT_PAD = 128  # filters are zero-padded to a multiple of the largest N tile
@@ -335,7 +336,15 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
+    if T.ENABLED:            # FCP_BOUNDARY=torch: the same launch through the registered PyTorch custom op
+        T.load().conv2d(x.buf, x.c0, pc.cin, pc.w, pc.bias, pc.wscale, None if res1 is None else res1.buf,
+                        0 if res1 is None else res1.c0, None if res2 is None else res2.buf, 0 if res2 is None else res2.c0,
+                        out.buf, out.c0, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, float(act_slope), float(alpha), float(alpha2),
+                        bool(res1_pre), pc.precision, x.fmt, out.fmt, d.res1_fmt, d.res2_fmt, bool(in_up2), bool(pc.cin4),
+                        int(d.tile_m), int(d.tile_n), None if x2 is None else x2.buf, 0 if x2 is None else x2.c0,
+                        0 if x2 is None else x2.c, int(x2_stride), int(d.flags))
+    else:
+        N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
     if timing is not None:
         e1.record()
         timing.append((e0, e1, pc.flops_per_pixel * m))
@@ -363,26 +372,32 @@ def bottleneck_chain(pc2: PackedConv, pc3: PackedConv, pc1n: PackedConv, t1: Act
     assert t1.fmt == 1 and res.fmt == 1 and t1.c == 64 and res.c == 256
     assert (t1.n, t1.h, t1.w) == (res.n, res.h, res.w)
     dev = t1.buf.device
-    if out is None:
-        out = Act.empty(t1.n, t1.h, t1.w, 256, dev, 1)
-    if t1n is None:
-        t1n = Act.empty(t1.n, t1.h, t1.w, pc1n.cout, dev, 1)
-    assert out.fmt == 1 and t1n.fmt == 1 and (out.n, out.h, out.w, out.c) == (t1.n, t1.h, t1.w, 256)
-    assert (t1n.n, t1n.h, t1n.w, t1n.c) == (t1.n, t1.h, t1.w, pc1n.cout)
-    d = N.ChainDesc()
-    d.t1, d.res, d.out, d.t1n = t1.ptr(), res.ptr(), out.ptr(), t1n.ptr()
-    d.w2, d.ws2, d.b2 = N.ptr(pc2.w), N.ptr(pc2.wscale), N.ptr(pc2.bias)
-    d.w3, d.ws3, d.b3 = N.ptr(pc3.w), N.ptr(pc3.wscale), N.ptr(pc3.bias)
-    d.w1n, d.ws1n, d.b1n = N.ptr(pc1n.w), N.ptr(pc1n.wscale), N.ptr(pc1n.bias)
-    d.n, d.h, d.w, d.c, d.cn = t1.n, t1.h, t1.w, 64, pc1n.cout
-    d.t1_ld, d.res_ld, d.out_ld, d.t1n_ld = t1.ld, res.ld, out.ld, t1n.ld
     m = t1.n * t1.h * t1.w
     flops = (pc2.flops_per_pixel + pc3.flops_per_pixel + pc1n.flops_per_pixel) * m
     timing = ConvStats.timing
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
+    if T.ENABLED and out is None and t1n is None:
+        # FCP_BOUNDARY=torch: the registered custom op allocates and returns both tensors
+        o, t = T.load().bottleneck_chain(t1.buf, t1.c0, res.buf, res.c0, pc2.w, pc2.wscale, pc2.bias, pc3.w, pc3.wscale,
+                                         pc3.bias, pc1n.w, pc1n.wscale, pc1n.bias, pc1n.cout)
+        out, t1n = Act(o, fmt=1), Act(t, fmt=1)
+    else:
+        if out is None:
+            out = Act.empty(t1.n, t1.h, t1.w, 256, dev, 1)
+        if t1n is None:
+            t1n = Act.empty(t1.n, t1.h, t1.w, pc1n.cout, dev, 1)
+        assert out.fmt == 1 and t1n.fmt == 1 and (out.n, out.h, out.w, out.c) == (t1.n, t1.h, t1.w, 256)
+        assert (t1n.n, t1n.h, t1n.w, t1n.c) == (t1.n, t1.h, t1.w, pc1n.cout)
+        d = N.ChainDesc()
+        d.t1, d.res, d.out, d.t1n = t1.ptr(), res.ptr(), out.ptr(), t1n.ptr()
+        d.w2, d.ws2, d.b2 = N.ptr(pc2.w), N.ptr(pc2.wscale), N.ptr(pc2.bias)
+        d.w3, d.ws3, d.b3 = N.ptr(pc3.w), N.ptr(pc3.wscale), N.ptr(pc3.bias)
+        d.w1n, d.ws1n, d.b1n = N.ptr(pc1n.w), N.ptr(pc1n.wscale), N.ptr(pc1n.bias)
+        d.n, d.h, d.w, d.c, d.cn = t1.n, t1.h, t1.w, 64, pc1n.cout
+        d.t1_ld, d.res_ld, d.out_ld, d.t1n_ld = t1.ld, res.ld, out.ld, t1n.ld
+        N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
     if timing is not None:
         e1.record()
         timing.append((e0, e1, flops))

@@ -21,6 +21,7 @@ import torch
 
 from . import _native as N
 from . import engine as E
+from . import torch_ops as T
 from .weights import load_state_dict
 
 STRATEGIES = {"all": 0, "best": 1, "largest": 2}
@@ -242,6 +243,8 @@ class RetinaFace:
         if want_dense:
             dense = (torch.empty((n, P), dtype=f32, device=dev), torch.empty((n, P, 4), dtype=f32, device=dev),
                      torch.empty((n, P, 10), dtype=f32, device=dev))
+        if T.ENABLED and not want_dense:
+            return self._postprocess_ops(heads, n, h, w, P, paddings, max_faces)
         st = N.stream_ptr()
         lib = N.lib()
         N.check(lib.fcp_retina_decode(heads[0].ptr(), heads[1].ptr(), heads[2].ptr(), n, h, w,
@@ -265,6 +268,25 @@ class RetinaFace:
                    cand_box=cand_box, cand_ldm=cand_ldm, cand_prior=cand_prior, cand_count=cand_count,
                    heads=heads, dense=dense, max_faces=max_faces)
         return out
+
+    def _postprocess_ops(self, heads, n, h, w, P, paddings, max_faces):
+        """decode -> NMS / strategy -> gather through ``torch.ops.fcp`` (FCP_BOUNDARY=torch); same result dict."""
+        ops = T.load()
+        dev = heads[0].buf.device
+        cand_score, cand_box, cand_ldm, cand_prior, cand_count = ops.retina_decode(
+            heads[0].buf, heads[1].buf, heads[2].buf, h, w, float(self.vis_threshold), float(self.variance[0]),
+            float(self.variance[1]))
+        keep_pos, keep_count, sel_pos, sel_count = ops.nms_select(cand_score, cand_box, cand_count, float(self.nms_threshold),
+                                                                  STRATEGIES[self.strategy])
+        if max_faces is None:
+            max_faces = n if self.strategy != "all" else int(sel_count.sum().item())
+        max_faces = max(int(max_faces), 1)
+        if paddings is not None:
+            paddings = paddings.to(device=dev, dtype=torch.int32).contiguous()
+        landmarks, img_idx, face_offset = ops.gather_faces(cand_ldm, sel_pos, sel_count, paddings, max_faces)
+        return dict(keep_pos=keep_pos, keep_count=keep_count, sel_pos=sel_pos, sel_count=sel_count, landmarks=landmarks,
+                    img_idx=img_idx, face_offset=face_offset, cand_score=cand_score, cand_box=cand_box, cand_ldm=cand_ldm,
+                    cand_prior=cand_prior, cand_count=cand_count, heads=heads, dense=(None, None, None), max_faces=max_faces)
 
     # ----------------------------------------------------------------- graphs
     def graphed(self, n: int, h: int, w: int, paddings: torch.Tensor | None = None):

@@ -1,0 +1,37 @@
+"""``torch.ops.fcp.*`` — the PyTorch-ROCm custom-op face of the native library (SURVEY.md 8b / north_star:
+"Python host code calling hand-written CDNA4 HIP kernels through PyTorch-ROCm custom ops").
+
+``csrc/libfcp_torch.so`` (built by ``build_native.py`` from ``csrc/torch_ops/fcp_torch_ops.cpp``) registers the ops with
+``TORCH_LIBRARY(fcp, ...)`` / ``TORCH_LIBRARY_IMPL(fcp, CUDA, ...)``: tensors in / out, outputs from torch's caching
+allocator, work enqueued on the current HIP stream, misuse -> ``RuntimeError`` via ``TORCH_CHECK``.  They are a veneer
+over the C ABI of ``include/fcp_hip.h`` (same kernels, same bits).  The host code calls the C ABI through ctypes by
+default (lower per-call overhead: ~70 launches per detection step); ``FCP_BOUNDARY=torch`` routes the convolution engine,
+the detector's post-processing and align / crop through the registered ops instead — both paths are tested to give
+identical tensors.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_torch.so")
+_loaded = False
+ENABLED = os.environ.get("FCP_BOUNDARY", "ctypes") == "torch"
+
+
+def load():
+    """Register the ops (once).  Raises when the library has not been built: there is no fallback."""
+    global _loaded
+    if not _loaded:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(f"torch op library not built: {LIB_PATH} is missing "
+                               f"(run `python face-crop-plus_amd/build_native.py`)")
+        torch.ops.load_library(LIB_PATH)
+        _loaded = True
+    return torch.ops.fcp
+
+
+OPS = ("conv2d", "bottleneck_chain", "retina_decode", "nms_select", "gather_faces", "similarity_from_5pt",
+       "warp_affine_u8", "bicubic_down4_round", "parse_argmax_hist")
