@@ -16,7 +16,7 @@ def load(path):
     d = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
         d.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"]})[r["Counter_Name"]] = float(r["Counter_Value"])
-    return [v for v in d.values() if any(k in v["name"] for k in ("conv_igemm", "conv3x3_halo", "stem_pool_kernel"))][-LAUNCHES:]
+    return [v for v in d.values() if any(k in v["name"] for k in ("conv_igemm", "conv3x3_halo", "stem_pool_kernel", "bneck_chain"))][-LAUNCHES:]
 
 
 import glob

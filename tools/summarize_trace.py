@@ -21,6 +21,6 @@ with open(dst, "w") as f:
         wg = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1) // max(1, int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1))
         f.write(f'"{name}",{wg},{(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:.1f}\n')
 wall = (int(rows[b]["Start_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e6
-is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_halo", "stem_pool_kernel"))
+is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_halo", "stem_pool_kernel", "bneck_chain"))
 conv = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg if is_conv(r)) / 1e6
 print(f"step: {len(seg)} launches, {wall:.3f} ms wall, conv engine {conv:.3f} ms in {sum(map(is_conv, seg))} launches")
