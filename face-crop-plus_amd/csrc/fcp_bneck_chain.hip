@@ -24,6 +24,15 @@
 // Arithmetic is that of the stand-alone kernels, instruction for instruction (al*bh + ah*bl + ah*bh per k-half,
 // K slices in ascending order, the same fp32 epilogue expressions, the same hi/lo split of every stored tensor), so
 // out and t1' are BIT-IDENTICAL to running the three convolutions separately (tests/test_chain_gpu.py).
+//
+// The same chunk loop also runs WITHOUT phase 1 ("pair": HAS_C2 = false) on 128-channel inputs, whose operand tile is
+// then fetched by LDS-DMA instead of being computed:
+//     out = relu(bn3(conv3_1x1(t)) [+ x])   128 -> NOUT;    t1' = relu(bn1'(conv1'_1x1(out)))   NOUT -> CN
+//   * NOUT = 512, with residual, CN = 128:  conv3 of a layer-2 identity block + conv1 of the next block: the 512-channel
+//     tensor (0.84 GB at the bench size) is not read back by a separate conv1 launch;
+//   * NOUT = 256, no residual, CN = 64:  layer1.0's conv3 + downsample (one K-concatenated 1x1 conv over [conv2 out |
+//     pooled stem]) + layer1.1's conv1.
+// 128 KiB of LDS, one workgroup per CU.
 #include "fcp_conv_common.h"
 
 using namespace fcp_conv;
@@ -45,22 +54,27 @@ struct ChainK {
   int ablate;   // profiling builds only (FCP_CHAIN_ABLATE): 1 no out stores, 2 no residual loads, 4 no phase-1 loop, 8 no chunk loop
 };
 
-constexpr int C = 64;                 // bottleneck width
+constexpr int C = 64;                 // bottleneck width of the variant with phase 1
 constexpr int ROWB = 128;             // bytes per LDS operand row: 32 hi + 32 lo binary16
 constexpr int STAGE = (BM + C) * ROWB;          // 24 KiB: one phase-1 stage (A rows then B rows)
-constexpr int R0_BYTES = 2 * STAGE;             // 48 KiB region: phase-1 stages | epilogue tiles | chunk buffers
-constexpr int T2_OFF = R0_BYTES;                // 32 KiB: conv2's output tile as operand image
-constexpr int LDS_BYTES = R0_BYTES + BM * C * 4;   // 80 KiB -> two workgroups per CU
 constexpr int CT_OFF = 0;                       // chunk loop: 128 x 32 fp32 epilogue tile, rewritten in place as T3 (16 KiB)
 constexpr int W1B_OFF = 16384;                  // chunk loop: K slice j of conv1' (CN rows x 128 B, <= 16 KiB)
-constexpr int W3B_OFF = 32768;                  // chunk loop: conv3 filter group, 2 x 8 KiB (double buffer)
-constexpr int NCH = 4 * C / 32;                 // 8 groups of 32 conv3 filters
+constexpr int W3B_OFF = 32768;                  // chunk loop: conv3 filter group, 2 x (CW * 128 B) (double buffer)
+// region 0 = phase-1 stages | epilogue tiles | chunk buffers; the operand tile T2 (BM x CW, 4 B per element) follows it
+constexpr int r0_bytes(int cw, bool has_c2) { return has_c2 ? 2 * STAGE : W3B_OFF + 2 * cw * 128; }
+constexpr int lds_bytes(int cw, bool has_c2) { return r0_bytes(cw, has_c2) + BM * cw * 4; }   // 80 KiB (two per CU) | 128 KiB
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 
-template <int CN>
-__global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
+template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES>
+__global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const ChainK p) {
+  static_assert(!HAS_C2 || CW == C, "phase 1 is written for 64-channel bottlenecks");
   constexpr int TN3 = CN / 32;
+  constexpr int CS = CW / 32;                       // K slices of conv3
+  constexpr int NCH = NOUT / 32;                    // groups of 32 conv3 filters
+  constexpr int W3CH = CW * 128;                    // bytes of one conv3 filter group in LDS
+  constexpr int T2_OFF = r0_bytes(CW, HAS_C2);
+  constexpr int NRES = HAS_RES ? 4 : 0;             // residual loads per chunk and thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
 
@@ -86,8 +100,8 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
   const int hw = p.h * p.w;
 
   // =========================================================================================== phase 1: 3x3 conv
-  f32x16 acc1[2];
-  {
+  if constexpr (HAS_C2) {
+    f32x16 acc1[2];
     constexpr int A_LD = BM / 32, B_LD = C / 32;
     const int wm = wave / 2, wn = wave % 2;                      // 2 x 2 waves of 64 x 32
     TapPiece tp[A_LD];
@@ -235,20 +249,31 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
       }
     }
     __syncthreads();                                             // T2 complete; the fp32 tile is dead
+  } else {
+    // ---- no conv2: the operand tile is the input itself (CS slices of 128 pixels x 128 B), by LDS-DMA
+    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t1), 0, p.t1_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+      const int m = tile_m * BM + lrow + 32 * i;
+      const unsigned ro = m < p.M ? ((unsigned)m * (unsigned)p.t1_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
+#pragma unroll
+      for (int sl = 0; sl < CS; ++sl)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(lds + T2_OFF + sl * BM * ROWB + wave_u * 8 * ROWB + 32 * i * ROWB),
+                                                 16, (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(sl * 128)), 0, 0, 0);
+    }
   }
 
   // ========================================================================== chunk loop: conv3 (+x, relu) and conv1'
   __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w3), 0, p.w3_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w1n), 0, p.w1n_bytes, 0x00020000);
-  // conv3 filter group j: 32 rows x 2 K slices.  Wave w moves slice w >> 1, rows (w & 1) * 16 + {0..7, 8..15}.
-  const int w3r = (wave_u & 1) * 16 + (lane >> 3);               // + 8 i
+  // conv3 filter group j: 32 rows x CS K slices = 4 CS pieces of 8 rows.  Wave w moves pieces w CS .. w CS + CS - 1.
   auto dma_w3 = [&](int j, int buf) {
-    char* dst = lds + W3B_OFF + buf * 8192 + (wave_u >> 1) * 4096 + (wave_u & 1) * 16 * ROWB;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = w3r + 8 * i;
-      const unsigned src = (unsigned)((j * 32 + r) * (C * 4) + (wave_u >> 1) * 128 + (((lane & 7) ^ swz(r)) << 4));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (__attribute__((address_space(3))) void*)(dst + 8 * i * ROWB), 16, (int)src, 0, 0, 0);
+    for (int i = 0; i < CS; ++i) {
+      const int g = wave_u * CS + i, sl = g >> 2, r = (g & 3) * 8 + (lane >> 3);
+      char* dst = lds + W3B_OFF + buf * W3CH + sl * 4096 + (g & 3) * 8 * ROWB;
+      const unsigned src = (unsigned)((j * 32 + r) * (CW * 4) + sl * 128 + (((lane & 7) ^ swz(r)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (__attribute__((address_space(3))) void*)dst, 16, (int)src, 0, 0, 0);
     }
   };
   // conv1' K slice j: CN rows.  Wave w moves rows w * CN/4 + 8 i + lane / 8.
@@ -257,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
 #pragma unroll
     for (int i = 0; i < CN / 32; ++i) {
       const int r = wave_u * (CN / 4) + 8 * i + (lane >> 3);
-      const unsigned src = (unsigned)(r * (4 * C * 4) + j * 128 + (((lane & 7) ^ swz(r)) << 4));
+      const unsigned src = (unsigned)(r * (NOUT * 4) + j * 128 + (((lane & 7) ^ swz(r)) << 4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + 8 * i * ROWB), 16, (int)src, 0, 0, 0);
     }
   };
@@ -286,6 +311,7 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
   //   [top]  W3 group j+1 (2 DMA), W1' slice j (CN/32 DMA)  |  [epilogue]  residual j+1 (4 loads)  |  [phase 3]  out j (4 stores)
   u32x4_t rhi[2], rlo[2];
   auto load_res = [&](int j) {
+    if constexpr (!HAS_RES) return;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const char* pb = reinterpret_cast<const char*>(p.res) + rm[it] * p.res_ld * 4 + j * 128 + eq * 16;
@@ -297,16 +323,16 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
   dma_w3(0, 0);
   if (nch > 0) load_res(0);
   float ws_l = p.ws3[l31], b_l = p.b3[l31];                      // this lane's conv3 channel of chunk 0 (MFMA layout: col = lane & 31)
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");               // the filter group has landed; the residual may still fly
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");    // the operand tile / filter group have landed; the residual may still fly
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
   for (int j = 0; j < nch; ++j) {
     // ---- phase 2 operands: T2 (A) and filter group j (B), both K slices
-    f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];                // [slice][k-half]
-    const char* b2base = lds + W3B_OFF + (j & 1) * 8192 + l31 * ROWB;
+    f16x8 ah[CS][2], al[CS][2], bh[CS][2], bl[CS][2];            // [slice][k-half]
+    const char* b2base = lds + W3B_OFF + (j & 1) * W3CH + l31 * ROWB;
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl)
+    for (int sl = 0; sl < CS; ++sl)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         ah[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offH[s]);
@@ -323,7 +349,7 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl)
+    for (int sl = 0; sl < CS; ++sl)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl][s], bh[sl][s], acc2, 0, 0, 0);
@@ -361,10 +387,11 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
       const f32x4 b = *reinterpret_cast<const f32x4*>(crow + (((4 + eq) ^ sw) << 4));
       float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
       float r[8];
-      join8(rhi[it], rlo[it], r);
+      if constexpr (HAS_RES) join8(rhi[it], rlo[it], r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float x = v[e] + r[e];
+        float x = v[e];
+        if constexpr (HAS_RES) x += r[e];
         x = x >= 0.f ? x : x * 0.f;
         v[e] = x * 1.f;
       }
@@ -376,49 +403,51 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
     if (j + 1 < NCH) load_res(j + 1);                            // the registers are free again: next chunk's residual
     __builtin_amdgcn_sched_barrier(0);
     // W1' slice j (issued at the top, older than the 4 residual loads just issued) must have landed
-    if (j + 1 < NCH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (j + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // ---- phase 3: acc3 += T3 . W1'[:, slice j]^T
-    f16x8 ch[2], cl[2], dh[2][TN3], dl[2][TN3];
+    // ---- phase 3: acc3 += T3 . W1'[:, slice j]^T, one k-half at a time (fragment registers: CN = 128 has none to spare);
+    //      the chunk's `out` stores are issued behind the first k-half's fragment reads
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      ch[s] = *reinterpret_cast<const f16x8*>(a3base + offH[s]);
-      cl[s] = *reinterpret_cast<const f16x8*>(a3base + offL[s]);
+      f16x8 ch, cl, dh[TN3], dl[TN3];
+      ch = *reinterpret_cast<const f16x8*>(a3base + offH[s]);
+      cl = *reinterpret_cast<const f16x8*>(a3base + offL[s]);
 #pragma unroll
       for (int t = 0; t < TN3; ++t) {
-        dh[s][t] = *reinterpret_cast<const f16x8*>(lds + W1B_OFF + (t * 32 + l31) * ROWB + offH[s]);
-        dl[s][t] = *reinterpret_cast<const f16x8*>(lds + W1B_OFF + (t * 32 + l31) * ROWB + offL[s]);
+        dh[t] = *reinterpret_cast<const f16x8*>(lds + W1B_OFF + (t * 32 + l31) * ROWB + offH[s]);
+        dl[t] = *reinterpret_cast<const f16x8*>(lds + W1B_OFF + (t * 32 + l31) * ROWB + offL[s]);
       }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+      if (s == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const long m = em0 + 64 * it;
-      if (m < p.M && !FCP_ABLATE(p, 1)) {
-        char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + j * 128 + eq * 16;
-        if (p.nt_store) {
-          __builtin_nontemporal_store(ohi[it], reinterpret_cast<u32x4_t*>(ob));
-          __builtin_nontemporal_store(olo[it], reinterpret_cast<u32x4_t*>(ob + 64));
-        } else {
-          *reinterpret_cast<u32x4_t*>(ob) = ohi[it];
-          *reinterpret_cast<u32x4_t*>(ob + 64) = olo[it];
+        for (int it = 0; it < 2; ++it) {
+          const long m = em0 + 64 * it;
+          if (m < p.M && !FCP_ABLATE(p, 1)) {
+            char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + j * 128 + eq * 16;
+            if (p.nt_store) {
+              __builtin_nontemporal_store(ohi[it], reinterpret_cast<u32x4_t*>(ob));
+              __builtin_nontemporal_store(olo[it], reinterpret_cast<u32x4_t*>(ob + 64));
+            } else {
+              *reinterpret_cast<u32x4_t*>(ob) = ohi[it];
+              *reinterpret_cast<u32x4_t*>(ob + 64) = olo[it];
+            }
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int t = 0; t < TN3; ++t) {
+        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, dh[t], acc3[t], 0, 0, 0);
+        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dl[t], acc3[t], 0, 0, 0);
+        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dh[t], acc3[t], 0, 0, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int t = 0; t < TN3; ++t) {
-        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[s], dh[s][t], acc3[t], 0, 0, 0);
-        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[s], dl[s][t], acc3[t], 0, 0, 0);
-        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[s], dh[s][t], acc3[t], 0, 0, 0);
-      }
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                // T3, W1' slice and filter group j are dead
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -474,10 +503,11 @@ __global__ void __launch_bounds__(256, 2) bneck_chain_c64(const ChainK p) {
   }
 }
 
-template <int CN>
+template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES>
 int launch(const ChainK& k, hipStream_t s) {
-  FCP_LDS_OPT_IN((&bneck_chain_c64<CN>), LDS_BYTES);
-  hipLaunchKernelGGL((bneck_chain_c64<CN>), dim3(fcp_cdiv(k.M, BM)), dim3(256), LDS_BYTES, s, k);
+  constexpr int LDS = lds_bytes(CW, HAS_C2);
+  FCP_LDS_OPT_IN((&bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES>), LDS);
+  hipLaunchKernelGGL((bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES>), dim3(fcp_cdiv(k.M, BM)), dim3(256), LDS, s, k);
   FCP_LAUNCH_OK();
   return 0;
 }
@@ -486,25 +516,32 @@ int launch(const ChainK& k, hipStream_t s) {
 
 extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t stream) {
   FCP_REQUIRE(d != nullptr, "chain: null descriptor");
-  FCP_REQUIRE(d->t1 && d->w2 && d->ws2 && d->b2 && d->w3 && d->ws3 && d->b3 && d->res && d->out && d->w1n && d->ws1n &&
-              d->b1n && d->t1n, "chain: null pointer (all three convolutions carry folded-BN bias and filter scales)");
-  FCP_REQUIRE(d->c == 64, "chain: bottleneck width %d not supported (64: ResNet-50 layer 1)", d->c);
-  FCP_REQUIRE(d->cn == 64 || d->cn == 128, "chain: next conv1 must have 64 or 128 filters (got %d)", d->cn);
+  FCP_REQUIRE(d->t1 && d->w3 && d->ws3 && d->b3 && d->out && d->w1n && d->ws1n && d->b1n && d->t1n,
+              "chain: null pointer (every convolution carries folded-BN bias and filter scales)");
+  const bool has_c2 = d->w2 != nullptr;
+  FCP_REQUIRE(!has_c2 || (d->ws2 && d->b2), "chain: conv2 needs its scales and bias");
+  // supported shapes: (c 64, conv2, nout 256, residual, cn 64 | 128)   (c 128, no conv2, nout 512, residual, cn 128)
+  //                   (c 128, no conv2, nout 256, no residual, cn 64)
+  const int variant = (has_c2 && d->c == 64 && d->nout == 256 && d->res && (d->cn == 64 || d->cn == 128)) ? (d->cn == 64 ? 1 : 2)
+                    : (!has_c2 && d->c == 128 && d->nout == 512 && d->res && d->cn == 128) ? 3
+                    : (!has_c2 && d->c == 128 && d->nout == 256 && !d->res && d->cn == 64) ? 4 : 0;
+  FCP_REQUIRE(variant != 0, "chain: unsupported shape (c %d, conv2 %d, nout %d, residual %d, cn %d)", d->c, (int)has_c2, d->nout,
+              d->res != nullptr, d->cn);
   FCP_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "chain: bad sizes");
   const long M = (long)d->n * d->h * d->w;
   FCP_REQUIRE(M < (1L << 31), "chain: too many pixels");
   auto aligned = [](const void* p, int ld) { return ((uintptr_t)p & 127) == 0 && ld % 32 == 0; };
-  FCP_REQUIRE(aligned(d->t1, d->t1_ld) && aligned(d->res, d->res_ld) && aligned(d->out, d->out_ld) && aligned(d->t1n, d->t1n_ld),
+  FCP_REQUIRE(aligned(d->t1, d->t1_ld) && (!d->res || aligned(d->res, d->res_ld)) && aligned(d->out, d->out_ld) && aligned(d->t1n, d->t1n_ld),
               "chain: tensors are split32 views: 128-byte aligned, channel stride a multiple of 32");
-  FCP_REQUIRE(d->t1_ld >= 64 && d->res_ld >= 256 && d->out_ld >= 256 && d->t1n_ld >= d->cn, "chain: channel strides too small");
+  FCP_REQUIRE(d->t1_ld >= d->c && (!d->res || d->res_ld >= d->nout) && d->out_ld >= d->nout && d->t1n_ld >= d->cn, "chain: channel strides too small");
   const unsigned long t1_bytes = (unsigned long)M * d->t1_ld * 4ul;
   FCP_REQUIRE(t1_bytes < 0xFFFFFFF0ul, "chain: t1 must be below 4 GiB");
   ChainK k;
   k.t1 = d->t1; k.t1_bytes = (unsigned)t1_bytes; k.t1_ld = d->t1_ld;
   k.w2 = reinterpret_cast<const float*>(d->w2); k.w2_bytes = 128u * 9 * 64 * 4; k.ws2 = d->ws2; k.b2 = d->b2;
-  k.w3 = reinterpret_cast<const float*>(d->w3); k.w3_bytes = 256u * 64 * 4; k.ws3 = d->ws3; k.b3 = d->b3;
+  k.w3 = reinterpret_cast<const float*>(d->w3); k.w3_bytes = (unsigned)(d->nout * d->c * 4); k.ws3 = d->ws3; k.b3 = d->b3;
   k.res = d->res; k.res_ld = d->res_ld; k.out = d->out; k.out_ld = d->out_ld;
-  k.w1n = reinterpret_cast<const float*>(d->w1n); k.w1n_bytes = 128u * 256 * 4; k.ws1n = d->ws1n; k.b1n = d->b1n;
+  k.w1n = reinterpret_cast<const float*>(d->w1n); k.w1n_bytes = (unsigned)(128 * d->nout * 4); k.ws1n = d->ws1n; k.b1n = d->b1n;
   k.t1n = d->t1n; k.t1n_ld = d->t1n_ld;
   k.n = d->n; k.h = d->h; k.w = d->w; k.M = (int)M;
   static const int nt_env = getenv("FCP_NT_STORE") ? atoi(getenv("FCP_NT_STORE")) : 1;
@@ -515,5 +552,11 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
 #else
   k.ablate = 0;
 #endif
-  return d->cn == 64 ? launch<64>(k, (hipStream_t)stream) : launch<128>(k, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  switch (variant) {
+    case 1: return launch<64, 64, 256, true, true>(k, s);
+    case 2: return launch<128, 64, 256, true, true>(k, s);
+    case 3: return launch<128, 128, 512, false, true>(k, s);
+    default: return launch<64, 128, 256, false, false>(k, s);
+  }
 }

@@ -92,22 +92,30 @@ Tensor conv2d(const Tensor& x, int64_t x_c0, int64_t cin, const Tensor& w, const
   return out;
 }
 
-std::tuple<Tensor, Tensor> bottleneck_chain(const Tensor& t1, int64_t t1_c0, const Tensor& res, int64_t res_c0, const Tensor& w2,
-                                            const Tensor& ws2, const Tensor& b2, const Tensor& w3, const Tensor& ws3,
+std::tuple<Tensor, Tensor> bottleneck_chain(const Tensor& t1, int64_t t1_c0, const c10::optional<Tensor>& res, int64_t res_c0,
+                                            const c10::optional<Tensor>& w2, const c10::optional<Tensor>& ws2,
+                                            const c10::optional<Tensor>& b2, const Tensor& w3, const Tensor& ws3,
                                             const Tensor& b3, const Tensor& w1n, const Tensor& ws1n, const Tensor& b1n,
-                                            int64_t cn) {
-  dev(t1, "t1", at::kFloat); dev(res, "res", at::kFloat);
-  TORCH_CHECK(t1.dim() == 4 && res.dim() == 4 && t1_c0 + 64 <= t1.size(3) && res_c0 + 256 <= res.size(3),
-              "t1 (n,h,w,>=64) / res (n,h,w,>=256) split32 buffers");
-  Tensor out = at::empty({t1.size(0), t1.size(1), t1.size(2), 256}, t1.options());
+                                            int64_t c, int64_t nout, int64_t cn) {
+  dev(t1, "t1", at::kFloat);
+  TORCH_CHECK(t1.dim() == 4 && t1_c0 + c <= t1.size(3), "t1 (n,h,w,>=c) split32 buffer");
+  const bool has_res = res.has_value() && res->defined();
+  if (has_res) {
+    dev(*res, "res", at::kFloat);
+    TORCH_CHECK(res->dim() == 4 && res_c0 + nout <= res->size(3), "res (n,h,w,>=nout) split32 buffer");
+  }
+  Tensor out = at::empty({t1.size(0), t1.size(1), t1.size(2), nout}, t1.options());
   Tensor t1n = at::empty({t1.size(0), t1.size(1), t1.size(2), cn}, t1.options());
   fcp_chain_desc d = {};
-  d.t1 = t1.data_ptr<float>() + t1_c0; d.res = res.data_ptr<float>() + res_c0; d.out = out.data_ptr<float>(); d.t1n = t1n.data_ptr<float>();
-  d.w2 = w2.data_ptr(); d.ws2 = dev(ws2, "ws2", at::kFloat).data_ptr<float>(); d.b2 = dev(b2, "b2", at::kFloat).data_ptr<float>();
+  d.t1 = t1.data_ptr<float>() + t1_c0; d.out = out.data_ptr<float>(); d.t1n = t1n.data_ptr<float>();
+  if (has_res) { d.res = res->data_ptr<float>() + res_c0; d.res_ld = (int)res->size(3); }
+  if (w2.has_value() && w2->defined()) {
+    d.w2 = w2->data_ptr(); d.ws2 = optp<float>(ws2, "ws2", at::kFloat); d.b2 = optp<float>(b2, "b2", at::kFloat);
+  }
   d.w3 = w3.data_ptr(); d.ws3 = dev(ws3, "ws3", at::kFloat).data_ptr<float>(); d.b3 = dev(b3, "b3", at::kFloat).data_ptr<float>();
   d.w1n = w1n.data_ptr(); d.ws1n = dev(ws1n, "ws1n", at::kFloat).data_ptr<float>(); d.b1n = dev(b1n, "b1n", at::kFloat).data_ptr<float>();
-  d.n = (int)t1.size(0); d.h = (int)t1.size(1); d.w = (int)t1.size(2); d.c = 64; d.cn = (int)cn;
-  d.t1_ld = (int)t1.size(3); d.res_ld = (int)res.size(3); d.out_ld = 256; d.t1n_ld = (int)cn;
+  d.n = (int)t1.size(0); d.h = (int)t1.size(1); d.w = (int)t1.size(2); d.c = (int)c; d.cn = (int)cn; d.nout = (int)nout;
+  d.t1_ld = (int)t1.size(3); d.out_ld = (int)nout; d.t1n_ld = (int)cn;
   ok(fcp_bottleneck_chain_f16x3(&d, cur_stream()), "fcp::bottleneck_chain");
   return {out, t1n};
 }
@@ -209,8 +217,8 @@ TORCH_LIBRARY(fcp, m) {
         "int res2_c0, Tensor(a!)? out, int out_c0, int cout, int kh, int kw, int stride, int pad, float act_slope, float alpha, "
         "float alpha2, bool res1_pre, int precision, int in_fmt, int out_fmt, int res1_fmt, int res2_fmt, bool in_up2, "
         "bool cin4, int tile_m, int tile_n, Tensor? x2, int x2_c0, int cin2, int x2_stride, int flags) -> Tensor");
-  m.def("bottleneck_chain(Tensor t1, int t1_c0, Tensor res, int res_c0, Tensor w2, Tensor ws2, Tensor b2, Tensor w3, Tensor ws3, Tensor b3, "
-        "Tensor w1n, Tensor ws1n, Tensor b1n, int cn) -> (Tensor, Tensor)");
+  m.def("bottleneck_chain(Tensor t1, int t1_c0, Tensor? res, int res_c0, Tensor? w2, Tensor? ws2, Tensor? b2, Tensor w3, Tensor ws3, "
+        "Tensor b3, Tensor w1n, Tensor ws1n, Tensor b1n, int c, int nout, int cn) -> (Tensor, Tensor)");
   m.def("retina_decode(Tensor head0, Tensor head1, Tensor head2, int img_h, int img_w, float vis, float var0, float var1) "
         "-> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("nms_select(Tensor cand_score, Tensor cand_box, Tensor cand_count, float nms_threshold, int strategy) "

@@ -354,49 +354,59 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     return out
 
 
-def chain_supported(pc2: PackedConv, pc3: PackedConv, pc1n: PackedConv) -> bool:
-    """Shapes ``fcp_bottleneck_chain_f16x3`` covers: 64-wide bottleneck (3x3 64->64 / 1, 1x1 64->256), next conv1
-    1x1 256 -> 64 | 128, all packed for the fp16x3 path with folded-BN bias."""
-    return (all(pc.precision == 1 and pc.bias is not None and not pc.cin4 for pc in (pc2, pc3, pc1n))
-            and (pc2.cin, pc2.cout, pc2.kh, pc2.kw, pc2.stride, pc2.pad) == (64, 64, 3, 3, 1, 1)
-            and (pc3.cin, pc3.cout, pc3.kh, pc3.kw, pc3.stride, pc3.pad) == (64, 256, 1, 1, 1, 0)
-            and (pc1n.cin, pc1n.kh, pc1n.kw, pc1n.stride, pc1n.pad) == (256, 1, 1, 1, 0) and pc1n.cout in (64, 128))
+def chain_supported(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, residual: bool = True) -> bool:
+    """Shapes ``fcp_bottleneck_chain_f16x3`` covers, all packed for the fp16x3 path with folded-BN bias:
+    * with conv2: 64-wide bottleneck (3x3 64->64 / 1, 1x1 64->256 + residual), next conv1 1x1 256 -> 64 | 128;
+    * pair (``pc2`` None): 1x1 128->512 + residual, next conv1 512->128  (layer-2 identity blocks), or
+      1x1 128->256 without residual, next conv1 256->64  (layer1.0's conv3 + downsample K-concat, layer1.1.conv1)."""
+    convs = [pc for pc in (pc2, pc3, pc1n) if pc is not None]
+    if not all(pc.precision == 1 and pc.bias is not None and not pc.cin4 for pc in convs):
+        return False
+    one = lambda pc, cin, cout: (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad) == (cin, cout, 1, 1, 1, 0)
+    if pc2 is not None:
+        return ((pc2.cin, pc2.cout, pc2.kh, pc2.kw, pc2.stride, pc2.pad) == (64, 64, 3, 3, 1, 1) and residual
+                and one(pc3, 64, 256) and (one(pc1n, 256, 64) or one(pc1n, 256, 128)))
+    if residual:
+        return one(pc3, 128, 512) and one(pc1n, 512, 128)
+    return one(pc3, 128, 256) and one(pc1n, 256, 64)
 
 
-def bottleneck_chain(pc2: PackedConv, pc3: PackedConv, pc1n: PackedConv, t1: Act, res: Act,
+def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, t1: Act, res: Act | None,
                      out: Act | None = None, t1n: Act | None = None):
-    """One launch for  out = relu(conv3(relu(conv2(t1))) + res),  t1n = relu(conv1n(out))  (BatchNorm folded): conv2 /
-    conv3 of an identity bottleneck and conv1 of the next block.  Bit-identical to the three ``conv`` calls.
-    Returns (out, t1n), both split32."""
-    assert chain_supported(pc2, pc3, pc1n), "bottleneck_chain: unsupported shapes"
-    assert t1.fmt == 1 and res.fmt == 1 and t1.c == 64 and res.c == 256
-    assert (t1.n, t1.h, t1.w) == (res.n, res.h, res.w)
+    """One launch for  out = relu(conv3(relu(conv2(t1))) [+ res]),  t1n = relu(conv1n(out))  (BatchNorm folded): conv2 /
+    conv3 of a bottleneck and conv1 of the next block; ``pc2`` None: the pair forms (no conv2, see ``chain_supported``).
+    Bit-identical to the separate ``conv`` calls.  Returns (out, t1n), both split32."""
+    assert chain_supported(pc2, pc3, pc1n, res is not None), "bottleneck_chain: unsupported shapes"
+    assert t1.fmt == 1 and t1.c == pc3.cin and (res is None or (res.fmt == 1 and res.c == pc3.cout))
+    assert res is None or (t1.n, t1.h, t1.w) == (res.n, res.h, res.w)
     dev = t1.buf.device
     m = t1.n * t1.h * t1.w
-    flops = (pc2.flops_per_pixel + pc3.flops_per_pixel + pc1n.flops_per_pixel) * m
+    flops = ((pc2.flops_per_pixel if pc2 is not None else 0) + pc3.flops_per_pixel + pc1n.flops_per_pixel) * m
     timing = ConvStats.timing
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    opt = lambda pc, f: None if pc is None else getattr(pc, f)
     if T.ENABLED and out is None and t1n is None:
         # FCP_BOUNDARY=torch: the registered custom op allocates and returns both tensors
-        o, t = T.load().bottleneck_chain(t1.buf, t1.c0, res.buf, res.c0, pc2.w, pc2.wscale, pc2.bias, pc3.w, pc3.wscale,
-                                         pc3.bias, pc1n.w, pc1n.wscale, pc1n.bias, pc1n.cout)
+        o, t = T.load().bottleneck_chain(t1.buf, t1.c0, None if res is None else res.buf, 0 if res is None else res.c0,
+                                         opt(pc2, "w"), opt(pc2, "wscale"), opt(pc2, "bias"), pc3.w, pc3.wscale, pc3.bias,
+                                         pc1n.w, pc1n.wscale, pc1n.bias, pc3.cin, pc3.cout, pc1n.cout)
         out, t1n = Act(o, fmt=1), Act(t, fmt=1)
     else:
         if out is None:
-            out = Act.empty(t1.n, t1.h, t1.w, 256, dev, 1)
+            out = Act.empty(t1.n, t1.h, t1.w, pc3.cout, dev, 1)
         if t1n is None:
             t1n = Act.empty(t1.n, t1.h, t1.w, pc1n.cout, dev, 1)
-        assert out.fmt == 1 and t1n.fmt == 1 and (out.n, out.h, out.w, out.c) == (t1.n, t1.h, t1.w, 256)
+        assert out.fmt == 1 and t1n.fmt == 1 and (out.n, out.h, out.w, out.c) == (t1.n, t1.h, t1.w, pc3.cout)
         assert (t1n.n, t1n.h, t1n.w, t1n.c) == (t1.n, t1.h, t1.w, pc1n.cout)
         d = N.ChainDesc()
-        d.t1, d.res, d.out, d.t1n = t1.ptr(), res.ptr(), out.ptr(), t1n.ptr()
-        d.w2, d.ws2, d.b2 = N.ptr(pc2.w), N.ptr(pc2.wscale), N.ptr(pc2.bias)
+        d.t1, d.res, d.out, d.t1n = t1.ptr(), (res.ptr() if res is not None else None), out.ptr(), t1n.ptr()
+        d.w2, d.ws2, d.b2 = N.ptr(opt(pc2, "w")), N.ptr(opt(pc2, "wscale")), N.ptr(opt(pc2, "bias"))
         d.w3, d.ws3, d.b3 = N.ptr(pc3.w), N.ptr(pc3.wscale), N.ptr(pc3.bias)
         d.w1n, d.ws1n, d.b1n = N.ptr(pc1n.w), N.ptr(pc1n.wscale), N.ptr(pc1n.bias)
-        d.n, d.h, d.w, d.c, d.cn = t1.n, t1.h, t1.w, 64, pc1n.cout
-        d.t1_ld, d.res_ld, d.out_ld, d.t1n_ld = t1.ld, res.ld, out.ld, t1n.ld
+        d.n, d.h, d.w, d.c, d.cn, d.nout = t1.n, t1.h, t1.w, pc3.cin, pc1n.cout, pc3.cout
+        d.t1_ld, d.res_ld, d.out_ld, d.t1n_ld = t1.ld, (res.ld if res is not None else 0), out.ld, t1n.ld
         N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
     if timing is not None:
         e1.record()

@@ -141,17 +141,22 @@ class RetinaFace:
             x = E.maxpool3x3s2(x, cat.slice(x.c, x.c))
         feats = []
         blocks, pre = p["blocks"], None
+        chain = bool(f) and self.fused_chain
         for bi, blk in enumerate(blocks):
             o = pre if pre is not None else E.conv(blk["c1"], x, act_slope=0.0, out_fmt=f)
             pre = None
             nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
-            if (f and self.fused_chain and blk["ds"] is None and not blk["feat"] and nxt is not None
+            if (chain and blk["ds"] is None and not blk["feat"] and nxt is not None
                     and E.chain_supported(blk["c2"], blk["c3"], nxt["c1"])):
+                # conv2 + conv3 (+ identity) of this block and conv1 of the next one in one launch (layer 1)
                 x, pre = E.bottleneck_chain(blk["c2"], blk["c3"], nxt["c1"], o, x)   # pre: next block's conv1 output
                 continue
             if "c3ds" in blk and blk["c2"].stride == 1:
                 E.conv(blk["c2"], o, cat.slice(0, o.c), act_slope=0.0)
-                x = E.conv(blk["c3ds"], cat, act_slope=0.0, out_fmt=f)
+                if chain and nxt is not None and E.chain_supported(None, blk["c3ds"], nxt["c1"], residual=False):
+                    x, pre = E.bottleneck_chain(None, blk["c3ds"], nxt["c1"], cat, None)   # conv3 + downsample, next conv1
+                else:
+                    x = E.conv(blk["c3ds"], cat, act_slope=0.0, out_fmt=f)
                 del cat
                 continue
             if "c3ds" in blk:
@@ -161,6 +166,10 @@ class RetinaFace:
                     feats.append(x)
                 continue
             o = E.conv(blk["c2"], o, act_slope=0.0, out_fmt=f)
+            if (chain and blk["ds"] is None and not blk["feat"] and nxt is not None
+                    and E.chain_supported(None, blk["c3"], nxt["c1"])):
+                x, pre = E.bottleneck_chain(None, blk["c3"], nxt["c1"], o, x)          # conv3 (+ identity) + next conv1 (layer 2)
+                continue
             idt = x if blk["ds"] is None else E.conv(blk["ds"], x, out_fmt=f)
             x = E.conv(blk["c3"], o, act_slope=0.0, res1=idt, res1_pre=True, out_fmt=f)
             if blk["feat"]:
@@ -202,9 +211,14 @@ class RetinaFace:
         bounds = [n * i // k for i in range(k + 1)]
         side = self._side_streams(dev, k)
         for st, a, b in zip(side, bounds[:-1], bounds[1:]):
+            tuned = len(E.Autotune.cache)
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 self.forward_heads(None, images_u8[a:b], [E.Act(hd.buf[a:b]) for hd in heads])
+            if len(E.Autotune.cache) != tuned:
+                # this sub-batch met untuned shapes (first call of a geometry): their tile candidates were timed with HIP
+                # events, so let it finish alone before the next sub-batch, with the same shapes, starts
+                st.synchronize()
         for st in side:
             cur.wait_stream(st)
         return heads

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 9
+#define FCP_ABI_VERSION 10
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -128,7 +128,13 @@ int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);
  * to three fcp_conv2d_nhwc_f32 launches.  Filters are ordinary precision-1 packs (pack_conv): w2
  * [128][9c] (3x3 / stride 1 / pad 1), w3 [4c][c], w1n [cn padded to 128][4c]; BatchNorm folded, so every conv
  * has a bias and a per-filter scale.  All tensors are split32 views (n, h, w, *_ld), 128-byte aligned,
- * *_ld % 32 == 0.  Supported: c = 64 (ResNet-50 layer 1), cn = 64 or 128.
+ * *_ld % 32 == 0.  Supported: c = 64 (ResNet-50 layer 1), nout = 256, cn = 64 or 128.
+ *
+ * Pair forms (w2 == NULL: no conv2, t1 is conv3's input itself, c = 128 channels):
+ *     out = relu(conv3_1x1(t1) * ws3 + b3 [+ res])    128 -> nout;     t1n = relu(conv1n_1x1(out) * ws1n + b1n)    nout -> cn
+ *   nout = 512, res != NULL, cn = 128   conv3 of a layer-2 identity block + conv1 of the next block
+ *   nout = 256, res == NULL, cn = 64    layer1.0: conv3 + downsample as one K-concatenated 1x1 conv over
+ *                                       [conv2 out | pooled stem] (engine.py packs it so), + layer1.1.conv1
  * ------------------------------------------------------------------------ */
 typedef struct fcp_chain_desc {
   const float* t1;    /* conv2's input: c channels */
@@ -140,6 +146,7 @@ typedef struct fcp_chain_desc {
   float* t1n;         /* cn channels */
   int32_t n, h, w, c, cn;
   int32_t t1_ld, res_ld, out_ld, t1n_ld;
+  int32_t nout;       /* conv3's filters: 4c with conv2; see the pair forms below */
 } fcp_chain_desc;
 
 int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* desc, fcp_stream_t stream);

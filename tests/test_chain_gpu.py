@@ -88,3 +88,44 @@ def test_detector_same_bits_with_and_without_chain(device):
     for ha, hb in zip(a["heads"], b["heads"]):
         assert torch.equal(ha.buf, hb.buf)
     assert torch.equal(a["landmarks"], b["landmarks"]) and torch.equal(a["face_offset"], b["face_offset"])
+
+
+@pytest.mark.parametrize("n,h,w,residual", [(2, 37, 45, True), (1, 16, 16, True), (3, 80, 80, True), (2, 33, 29, False),
+                                            (1, 160, 160, False)])
+def test_pair_equals_two_convs(n, h, w, residual, device):
+    """The pair forms (no conv2): conv3 (+ identity) + next conv1 on 128-channel inputs — layer-2 identity blocks
+    (128 -> 512 -> 128, residual) and layer1.0's K-concatenated conv3 + downsample with layer1.1.conv1
+    (128 -> 256 -> 64, no residual).  Bit-identical to the two stand-alone convolutions."""
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(n * 100 + h + int(residual))
+    nout, cn = (512, 128) if residual else (256, 64)
+    w3 = torch.randn(nout, 128, 1, 1, generator=g) * (2 / 128) ** 0.5
+    w1 = torch.randn(cn, nout, 1, 1, generator=g) * (2 / nout) ** 0.5
+    bn3, bn1 = _bn(nout, g), _bn(cn, g)
+    t = F.relu(torch.randn(n, 128, h, w, generator=g))
+    x = F.relu(torch.randn(n, nout, h, w, generator=g)) if residual else None
+    with E.default_precision("f16x3"):
+        pc3 = E.pack_conv(w3, None, bn3, 1, 0, device)
+        pc1 = E.pack_conv(w1, None, bn1, 1, 0, device)
+    assert E.chain_supported(None, pc3, pc1, residual)
+    nhwc = lambda v: v.permute(0, 2, 3, 1).contiguous().to(device)
+    ta = E.f32_to_split32(E.Act(nhwc(t)))
+    xa = E.f32_to_split32(E.Act(nhwc(x))) if residual else None
+    o3 = E.conv(pc3, ta, act_slope=0.0, res1=xa, res1_pre=True, out_fmt=1)
+    o1 = E.conv(pc1, o3, act_slope=0.0, out_fmt=1)
+    out, t1n = E.bottleneck_chain(None, pc3, pc1, ta, xa)
+    torch.cuda.synchronize()
+    assert torch.equal(out.buf, o3.buf) and torch.equal(t1n.buf, o1.buf)
+    r3 = _ref_bn(F.conv2d(t, w3), bn3)
+    r3 = F.relu(r3 + x) if residual else F.relu(r3)
+    r1 = F.relu(_ref_bn(F.conv2d(r3, w1), bn1))
+    for got, ref in ((out, r3), (t1n, r1)):
+        assert (got.nchw().cpu() - ref).abs().max().item() <= 3e-5 * float(ref.abs().max()) + 1e-6
+
+
+def test_chain_rejects_unsupported_shapes(device):
+    from face_crop_plus_amd import engine as E
+    with E.default_precision("f16x3"):
+        pc3 = E.pack_conv(torch.randn(1024, 256, 1, 1), torch.zeros(1024), None, 1, 0, device)
+        pc1 = E.pack_conv(torch.randn(256, 1024, 1, 1), torch.zeros(256), None, 1, 0, device)
+    assert not E.chain_supported(None, pc3, pc1)
