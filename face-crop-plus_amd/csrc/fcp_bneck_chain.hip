@@ -46,7 +46,7 @@ struct ChainK {
   const float* w2;  unsigned w2_bytes;  const float* ws2;  const float* b2;
   const float* w3;  unsigned w3_bytes;  const float* ws3;  const float* b3;
   const float* res; int res_ld;
-  float* out;       int out_ld;
+  float* out;       int out_ld;    unsigned out_bytes;
   const float* w1n; unsigned w1n_bytes; const float* ws1n; const float* b1n;
   float* t1n;       int t1n_ld;
   int n, h, w, M;
@@ -59,10 +59,13 @@ constexpr int ROWB = 128;             // bytes per LDS operand row: 32 hi + 32 l
 constexpr int STAGE = (BM + C) * ROWB;          // 24 KiB: one phase-1 stage (A rows then B rows)
 constexpr int CT_OFF = 0;                       // chunk loop: 128 x 32 fp32 epilogue tile, rewritten in place as T3 (16 KiB)
 constexpr int W1B_OFF = 16384;                  // chunk loop: K slice j of conv1' (CN rows x 128 B, <= 16 KiB)
-constexpr int W3B_OFF = 32768;                  // chunk loop: conv3 filter group, 2 x (CW * 128 B) (double buffer)
+// conv1' K slices are double-buffered wherever LDS allows (everything but the 80 KiB / CN = 128 variant): the next
+// slice's DMA can then be issued BEFORE the chunk's `out` stores, see the chunk loop
+constexpr bool w1_double(int cn, bool has_c2) { return !(has_c2 && cn == 128); }
+constexpr int w3b_off(int cn, bool has_c2) { return W1B_OFF + (w1_double(cn, has_c2) ? 2 : 1) * cn * 128; }   // conv3 filter groups, 2 x (CW * 128 B)
 // region 0 = phase-1 stages | epilogue tiles | chunk buffers; the operand tile T2 (BM x CW, 4 B per element) follows it
-constexpr int r0_bytes(int cw, bool has_c2) { return has_c2 ? 2 * STAGE : W3B_OFF + 2 * cw * 128; }
-constexpr int lds_bytes(int cw, bool has_c2) { return r0_bytes(cw, has_c2) + BM * cw * 4; }   // 80 KiB (two per CU) | 128 KiB
+constexpr int r0_bytes(int cw, int cn, bool has_c2) { return has_c2 ? 2 * STAGE : w3b_off(cn, has_c2) + 2 * cw * 128; }
+constexpr int lds_bytes(int cw, int cn, bool has_c2) { return r0_bytes(cw, cn, has_c2) + BM * cw * 4; }   // 80 KiB (two per CU) | 128-144 KiB
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 
@@ -73,7 +76,10 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
   constexpr int CS = CW / 32;                       // K slices of conv3
   constexpr int NCH = NOUT / 32;                    // groups of 32 conv3 filters
   constexpr int W3CH = CW * 128;                    // bytes of one conv3 filter group in LDS
-  constexpr int T2_OFF = r0_bytes(CW, HAS_C2);
+  constexpr int T2_OFF = r0_bytes(CW, CN, HAS_C2);
+  constexpr bool W1DB = w1_double(CN, HAS_C2);
+  constexpr int W3B_OFF = w3b_off(CN, HAS_C2);
+  static_assert(!HAS_C2 || W3B_OFF + 2 * W3CH <= 2 * STAGE, "chunk buffers must fit the phase-1 stage region");
   constexpr int NRES = HAS_RES ? 4 : 0;             // residual loads per chunk and thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
@@ -277,8 +283,8 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     }
   };
   // conv1' K slice j: CN rows.  Wave w moves rows w * CN/4 + 8 i + lane / 8.
-  auto dma_w1 = [&](int j) {
-    char* dst = lds + W1B_OFF + wave_u * (CN / 4) * ROWB;
+  auto dma_w1 = [&](int j, int buf) {
+    char* dst = lds + W1B_OFF + buf * (CN * ROWB) + wave_u * (CN / 4) * ROWB;
 #pragma unroll
     for (int i = 0; i < CN / 32; ++i) {
       const int r = wave_u * (CN / 4) + 8 * i + (lane >> 3);
@@ -299,16 +305,26 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
   const int eq = tid & 3;
   const int erow0 = tid >> 2;
   const long em0 = (long)tile_m * BM + erow0;
-  long rm[2];                                                    // residual / output pixel of the two items (clamped)
+  long rm[2];                                                    // residual pixel of the two items (clamped)
+  unsigned so[2];                                                // byte offset of the two items in `out`, 0xFFFFFFFF past the end
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    rm[it] = em0 + 64 * it < p.M ? em0 + 64 * it : (long)p.M - 1;
+    const long m = em0 + 64 * it;
+    rm[it] = m < p.M ? m : (long)p.M - 1;
     if (FCP_ABLATE(p, 2)) rm[it] = 0;
+    so[it] = (m < p.M && !FCP_ABLATE(p, 1)) ? (unsigned)(m * p.out_ld * 4 + eq * 16) : 0xFFFFFFFFu;
   }
-  // The residual x[:, 32 j ..] is requested ONE CHUNK AHEAD (right after chunk j - 1 has consumed its own), so its
-  // HBM round trip spans a whole chunk of matrix work; every wait below is counted so that neither these loads
-  // nor the stores of `out` (issued after them) are ever drained early.  vmem issue order per chunk:
-  //   [top]  W3 group j+1 (2 DMA), W1' slice j (CN/32 DMA)  |  [epilogue]  residual j+1 (4 loads)  |  [phase 3]  out j (4 stores)
+  __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+
+  // ---- vector-memory issue order.  vmcnt retires IN ORDER, and an `out` store to HBM takes microseconds to be
+  // acknowledged: any wait for a DMA issued AFTER a store also waits for that store.  So the DMAs a chunk needs are issued
+  // BEFORE the previous chunk's stores (phase 3 of chunk j issues  W1' slice j+1, W3 group j+2, THEN the stores of chunk j),
+  // the stores go through a buffer resource (out-of-range rows are dropped by the hardware: always exactly 4 per thread) and
+  // every wait is counted:
+  //     [phase 3 of j-1]  W1'(j) W3(j+1) | S(j-1) x4      [chunk j]  c(j+1) x2  R(j+1) x NRES   wait vmcnt(4 + 2 + NRES) -> W1'(j), W3(j+1) landed
+  // (c = the lane's scale / bias of the next chunk, R = the residual of the next chunk, both a chunk ahead).  The stores of
+  // chunk j-1 are first required to be complete at chunk j+1's wait: two chunks later.  Where LDS has no room for a second
+  // conv1' buffer (W1DB false), W1'(j) is issued at the top of chunk j instead and its wait also drains the stores of j-1.
   u32x4_t rhi[2], rlo[2];
   auto load_res = [&](int j) {
     if constexpr (!HAS_RES) return;
@@ -320,15 +336,19 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     }
   };
   const int nch = FCP_ABLATE(p, 8) ? 0 : NCH;
-  dma_w3(0, 0);
-  if (nch > 0) load_res(0);
   float ws_l = p.ws3[l31], b_l = p.b3[l31];                      // this lane's conv3 channel of chunk 0 (MFMA layout: col = lane & 31)
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");    // the operand tile / filter group have landed; the residual may still fly
+  asm volatile("" ::: "memory");
+  dma_w3(0, 0);
+  dma_w3(1, 1);
+  dma_w1(0, 0);
+  asm volatile("" ::: "memory");
+  if (nch > 0) load_res(0);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");    // operand tile / filter groups 0, 1 / conv1' slice 0 landed; the residual may fly
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
   for (int j = 0; j < nch; ++j) {
-    // ---- phase 2 operands: T2 (A) and filter group j (B), both K slices
+    // ---- phase 2 operands: T2 (A) and filter group j (B), all K slices
     f16x8 ah[CS][2], al[CS][2], bh[CS][2], bl[CS][2];            // [slice][k-half]
     const char* b2base = lds + W3B_OFF + (j & 1) * W3CH + l31 * ROWB;
 #pragma unroll
@@ -342,8 +362,7 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (j + 1 < NCH) dma_w3(j + 1, (j + 1) & 1);
-    dma_w1(j);
+    if constexpr (!W1DB) dma_w1(j, 0);                           // single conv1' buffer: free only now (see above)
     __builtin_amdgcn_sched_barrier(0);
     f32x16 acc2;
 #pragma unroll
@@ -367,10 +386,6 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
         const int piece = ((l31 & 4) ? (4 + q) : q) ^ swz(row);
         *reinterpret_cast<float*>(lds + CT_OFF + row * ROWB + (piece << 4) + (l31 & 3) * 4) = acc2[rr] * ws_l + b_l;
       }
-    }
-    if (j + 1 < NCH) {                                           // next chunk's channel constants (L2 hits, a chunk ahead)
-      ws_l = p.ws3[(j + 1) * 32 + l31];
-      b_l = p.b3[(j + 1) * 32 + l31];
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -400,16 +415,30 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
       *reinterpret_cast<u32x4_t*>(crow + (((4 + eq) ^ sw) << 4)) = olo[it];
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (j + 1 < NCH) load_res(j + 1);                            // the registers are free again: next chunk's residual
+    asm volatile("" ::: "memory");
+    const bool more = j + 1 < NCH;
+    if (more) {                                                  // a chunk ahead: the lane's channel constants, the residual
+      ws_l = p.ws3[(j + 1) * 32 + l31];
+      b_l = p.b3[(j + 1) * 32 + l31];
+      load_res(j + 1);
+    }
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    // W1' slice j (issued at the top, older than the 4 residual loads just issued) must have landed
-    if (j + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // conv1' slice j and filter group j + 1 must have landed; what was issued after them may stay in flight
+    if constexpr (W1DB) {
+      if (j == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NRES) : "memory");            // no stores yet
+      else if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 2 + NRES) : "memory");     // S(j-1) x4, c x2, R x NRES
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                  // last chunk: S(j-1) only
+    } else {
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NRES) : "memory");              // W1'(j) sits behind S(j-1): they drain too
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // ---- phase 3: acc3 += T3 . W1'[:, slice j]^T, one k-half at a time (fragment registers: CN = 128 has none to spare);
-    //      the chunk's `out` stores are issued behind the first k-half's fragment reads
+    // ---- phase 3: acc3 += T3 . W1'[:, slice j]^T, one k-half at a time (fragment registers: CN = 128 has none to spare).
+    //      Behind the first k-half's fragment reads: next DMAs, THEN this chunk's `out` stores.
+    const char* w1base = lds + W1B_OFF + (W1DB ? (j & 1) * (CN * ROWB) : 0);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       f16x8 ch, cl, dh[TN3], dl[TN3];
@@ -417,26 +446,25 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
       cl = *reinterpret_cast<const f16x8*>(a3base + offL[s]);
 #pragma unroll
       for (int t = 0; t < TN3; ++t) {
-        dh[t] = *reinterpret_cast<const f16x8*>(lds + W1B_OFF + (t * 32 + l31) * ROWB + offH[s]);
-        dl[t] = *reinterpret_cast<const f16x8*>(lds + W1B_OFF + (t * 32 + l31) * ROWB + offL[s]);
+        dh[t] = *reinterpret_cast<const f16x8*>(w1base + (t * 32 + l31) * ROWB + offH[s]);
+        dl[t] = *reinterpret_cast<const f16x8*>(w1base + (t * 32 + l31) * ROWB + offL[s]);
       }
       if (s == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (W1DB) {
+          if (more) dma_w1(j + 1, (j + 1) & 1);                  // its buffer was last read in phase 3 of chunk j - 1
+        }
+        if (j + 2 < NCH) dma_w3(j + 2, j & 1);                   // its buffer was last read in phase 2 of this chunk
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          const long m = em0 + 64 * it;
-          if (m < p.M && !FCP_ABLATE(p, 1)) {
-            char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + j * 128 + eq * 16;
-            if (p.nt_store) {
-              __builtin_nontemporal_store(ohi[it], reinterpret_cast<u32x4_t*>(ob));
-              __builtin_nontemporal_store(olo[it], reinterpret_cast<u32x4_t*>(ob + 64));
-            } else {
-              *reinterpret_cast<u32x4_t*>(ob) = ohi[it];
-              *reinterpret_cast<u32x4_t*>(ob + 64) = olo[it];
-            }
-          }
+          const unsigned o = so[it] == 0xFFFFFFFFu ? 0xFFFFFFFFu : so[it] + (unsigned)(j * 128);
+          __builtin_amdgcn_raw_buffer_store_b128(ohi[it], rs_out, o, 0, 2);                       // aux 2: nt (streamed once)
+          __builtin_amdgcn_raw_buffer_store_b128(olo[it], rs_out, o == 0xFFFFFFFFu ? o : o + 64u, 0, 2);
         }
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -505,7 +533,7 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
 
 template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES>
 int launch(const ChainK& k, hipStream_t s) {
-  constexpr int LDS = lds_bytes(CW, HAS_C2);
+  constexpr int LDS = lds_bytes(CW, CN, HAS_C2);
   FCP_LDS_OPT_IN((&bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES>), LDS);
   hipLaunchKernelGGL((bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES>), dim3(fcp_cdiv(k.M, BM)), dim3(256), LDS, s, k);
   FCP_LAUNCH_OK();
@@ -541,6 +569,9 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   k.w2 = reinterpret_cast<const float*>(d->w2); k.w2_bytes = 128u * 9 * 64 * 4; k.ws2 = d->ws2; k.b2 = d->b2;
   k.w3 = reinterpret_cast<const float*>(d->w3); k.w3_bytes = (unsigned)(d->nout * d->c * 4); k.ws3 = d->ws3; k.b3 = d->b3;
   k.res = d->res; k.res_ld = d->res_ld; k.out = d->out; k.out_ld = d->out_ld;
+  const unsigned long out_bytes = (unsigned long)M * d->out_ld * 4ul;
+  FCP_REQUIRE(out_bytes < 0xFFFFFFF0ul, "chain: out must span less than 4 GiB");
+  k.out_bytes = (unsigned)out_bytes;
   k.w1n = reinterpret_cast<const float*>(d->w1n); k.w1n_bytes = (unsigned)(128 * d->nout * 4); k.ws1n = d->ws1n; k.b1n = d->b1n;
   k.t1n = d->t1n; k.t1n_ld = d->t1n_ld;
   k.n = d->n; k.h = d->h; k.w = d->w; k.M = (int)M;
