@@ -301,30 +301,34 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
 
   const char* a2base = lds + T2_OFF + (wave * 32 + l31) * ROWB;   // + slice * BM * ROWB
   const char* a3base = lds + CT_OFF + (wave * 32 + l31) * ROWB;
-  // epilogue items of this thread: rows erow0, erow0 + 64; channel group eq (8 channels) of the 32-channel chunk
-  const int eq = tid & 3;
-  const int erow0 = tid >> 2;
+  // Epilogue items of this thread: rows erow0, erow0 + 16 OF THE WAVE'S OWN 32 ROWS, channel group eq (8 channels) of the
+  // 32-channel chunk.  A wave stages, finishes and re-reads (phase 3) only its own rows of the epilogue tile, so the three
+  // steps of a chunk need no workgroup barrier between them and the four waves may drift apart inside a chunk (one wave's
+  // MFMAs beside another's epilogue); what the waves share are the filter buffers: ONE barrier per chunk.
+  const int eq = lane & 3;
+  const int erow0 = wave * 32 + (lane >> 2);
   const long em0 = (long)tile_m * BM + erow0;
   long rm[2];                                                    // residual pixel of the two items (clamped)
   unsigned so[2];                                                // byte offset of the two items in `out`, 0xFFFFFFFF past the end
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const long m = em0 + 64 * it;
+    const long m = em0 + 16 * it;
     rm[it] = m < p.M ? m : (long)p.M - 1;
     if (FCP_ABLATE(p, 2)) rm[it] = 0;
     so[it] = (m < p.M && !FCP_ABLATE(p, 1)) ? (unsigned)(m * p.out_ld * 4 + eq * 16) : 0xFFFFFFFFu;
   }
   __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
-  // ---- vector-memory issue order.  vmcnt retires IN ORDER, and an `out` store to HBM takes microseconds to be
-  // acknowledged: any wait for a DMA issued AFTER a store also waits for that store.  So the DMAs a chunk needs are issued
-  // BEFORE the previous chunk's stores (phase 3 of chunk j issues  W1' slice j+1, W3 group j+2, THEN the stores of chunk j),
-  // the stores go through a buffer resource (out-of-range rows are dropped by the hardware: always exactly 4 per thread) and
-  // every wait is counted:
-  //     [phase 3 of j-1]  W1'(j) W3(j+1) | S(j-1) x4      [chunk j]  c(j+1) x2  R(j+1) x NRES   wait vmcnt(4 + 2 + NRES) -> W1'(j), W3(j+1) landed
-  // (c = the lane's scale / bias of the next chunk, R = the residual of the next chunk, both a chunk ahead).  The stores of
-  // chunk j-1 are first required to be complete at chunk j+1's wait: two chunks later.  Where LDS has no room for a second
-  // conv1' buffer (W1DB false), W1'(j) is issued at the top of chunk j instead and its wait also drains the stores of j-1.
+  // ---- vector-memory issue order.  vmcnt retires IN ORDER and an `out` store to HBM takes microseconds to be
+  // acknowledged, so no wait may sit behind a store it does not need.  Per chunk j (all counts per thread):
+  //     top(j):   wait for D(j) = {conv3 filter group j, conv1' slice j}; barrier; issue D(j+1) into the other buffers
+  //     phase 2, epilogue (consumes the residual R(j)); issue c(j+1) x2 (the lane's scale / bias), R(j+1) x NRES
+  //     phase 3; issue the stores S(j) x4 through a buffer resource (rows past the end are dropped by the hardware:
+  //     the count is exact)
+  // D(j+1) is a whole chunk ahead of its use and the ops younger than it at top(j+1) are exactly c(j+1), R(j+1), S(j):
+  // vmcnt(6 + NRES) waits for the DMAs without touching the stores, which are first forced two chunks after their
+  // issue.  Where LDS has no room for a second conv1' buffer (W1DB false) slice j is issued at top(j) and a second
+  // wait + barrier in front of phase 3 drains S(j-1) with it.
   u32x4_t rhi[2], rlo[2];
   auto load_res = [&](int j) {
     if constexpr (!HAS_RES) return;
@@ -339,15 +343,29 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
   float ws_l = p.ws3[l31], b_l = p.b3[l31];                      // this lane's conv3 channel of chunk 0 (MFMA layout: col = lane & 31)
   asm volatile("" ::: "memory");
   dma_w3(0, 0);
-  dma_w3(1, 1);
-  dma_w1(0, 0);
+  if constexpr (W1DB) dma_w1(0, 0);
   asm volatile("" ::: "memory");
   if (nch > 0) load_res(0);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");    // operand tile / filter groups 0, 1 / conv1' slice 0 landed; the residual may fly
-  __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
   for (int j = 0; j < nch; ++j) {
+    const bool more = j + 1 < NCH;
+    // ---- top: this chunk's filters have landed (everything younger may fly), every wave is done with chunk j - 1
+    // (W1DB false: group j was issued at top(j-1) and already forced by the wait in front of phase 3 of chunk j-1; the
+    //  ops younger than that wait — c(j), R(j), S(j-1) — may all stay in flight, which is the same count)
+    if (j == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NRES) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) dma_w3(j + 1, (j + 1) & 1);
+    if constexpr (W1DB) {
+      if (more) dma_w1(j + 1, (j + 1) & 1);
+    } else {
+      dma_w1(j, 0);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     // ---- phase 2 operands: T2 (A) and filter group j (B), all K slices
     f16x8 ah[CS][2], al[CS][2], bh[CS][2], bl[CS][2];            // [slice][k-half]
     const char* b2base = lds + W3B_OFF + (j & 1) * W3CH + l31 * ROWB;
@@ -360,10 +378,6 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
         bh[sl][s] = *reinterpret_cast<const f16x8*>(b2base + sl * 4096 + offH[s]);
         bl[sl][s] = *reinterpret_cast<const f16x8*>(b2base + sl * 4096 + offL[s]);
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!W1DB) dma_w1(j, 0);                           // single conv1' buffer: free only now (see above)
-    __builtin_amdgcn_sched_barrier(0);
     f32x16 acc2;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
@@ -375,9 +389,9 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[sl][s], acc2, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[sl][s], acc2, 0, 0, 0);
       }
-    // ---- acc2 * ws3 + b3 (per lane: one channel) -> fp32 tile.  Channel group q of a row is stored in the two
-    //      16-byte pieces the split32 image of that group will occupy (hi piece q ^ sw, lo piece (4 + q) ^ sw),
-    //      so the epilogue rewrites each item in place and needs no extra barrier.
+    // ---- acc2 * ws3 + b3 (per lane: one channel) -> the wave's rows of the fp32 tile.  Channel group q of a row is
+    //      stored in the two 16-byte pieces the split32 image of that group will occupy (hi piece q ^ sw, lo piece
+    //      (4 + q) ^ sw), so the epilogue rewrites each item in place.
     {
       const int q = l31 >> 3;
 #pragma unroll
@@ -387,15 +401,15 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
         *reinterpret_cast<float*>(lds + CT_OFF + row * ROWB + (piece << 4) + (l31 & 3) * 4) = acc2[rr] * ws_l + b_l;
       }
     }
+    // ---- epilogue of conv3 for this chunk (own rows: LDS accesses of one wave execute in order, no barrier):
+    //      out = relu(. + x) -> registers (stored in phase 3) and T3 (in place)
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- epilogue of conv3 for this chunk: out = relu(. + x) -> registers (stored in phase 3) and T3 (in place)
+    if constexpr (HAS_RES)     // keep the residual's first use HERE: hoisted into phase 2 it would be waited for a phase early
+      asm volatile("" : "+v"(rhi[0]), "+v"(rlo[0]), "+v"(rhi[1]), "+v"(rlo[1]));
     u32x4_t ohi[2], olo[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int row = erow0 + 64 * it;
+      const int row = erow0 + 16 * it;
       const int sw = swz(row);
       char* crow = lds + CT_OFF + row * ROWB;
       const f32x4 a = *reinterpret_cast<const f32x4*>(crow + ((eq ^ sw) << 4));
@@ -416,7 +430,6 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
-    const bool more = j + 1 < NCH;
     if (more) {                                                  // a chunk ahead: the lane's channel constants, the residual
       ws_l = p.ws3[(j + 1) * 32 + l31];
       b_l = p.b3[(j + 1) * 32 + l31];
@@ -424,20 +437,15 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    // conv1' slice j and filter group j + 1 must have landed; what was issued after them may stay in flight
-    if constexpr (W1DB) {
-      if (j == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NRES) : "memory");            // no stores yet
-      else if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 2 + NRES) : "memory");     // S(j-1) x4, c x2, R x NRES
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                  // last chunk: S(j-1) only
-    } else {
-      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NRES) : "memory");              // W1'(j) sits behind S(j-1): they drain too
+    if constexpr (!W1DB) {                                       // single conv1' buffer: slice j was issued at the top
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NRES) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- phase 3: acc3 += T3 . W1'[:, slice j]^T, one k-half at a time (fragment registers: CN = 128 has none to spare).
-    //      Behind the first k-half's fragment reads: next DMAs, THEN this chunk's `out` stores.
+    // ---- phase 3: acc3 += T3 . W1'[:, slice j]^T, one k-half at a time (fragment registers: CN = 128 has none to spare);
+    //      this chunk's `out` stores go out behind the first k-half's fragment reads
     const char* w1base = lds + W1B_OFF + (W1DB ? (j & 1) * (CN * ROWB) : 0);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -450,14 +458,8 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
         dl[t] = *reinterpret_cast<const f16x8*>(w1base + (t * 32 + l31) * ROWB + offL[s]);
       }
       if (s == 0) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (W1DB) {
-          if (more) dma_w1(j + 1, (j + 1) & 1);                  // its buffer was last read in phase 3 of chunk j - 1
-        }
-        if (j + 2 < NCH) dma_w3(j + 2, j & 1);                   // its buffer was last read in phase 2 of this chunk
         asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const unsigned o = so[it] == 0xFFFFFFFFu ? 0xFFFFFFFFu : so[it] + (unsigned)(j * 128);
@@ -475,11 +477,9 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                // T3, W1' slice and filter group j are dead
-    __builtin_amdgcn_sched_barrier(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
   // ================================================================================ conv1' epilogue -> t1' (HBM)
