@@ -3,13 +3,19 @@
 ``.predict(images, landmarks, indices)`` enhancing in place the images whose
 mean face-area factor is <= ``min_face_factor``).
 
-All 351 convolutions run on the fp32-MFMA engine with bias / LeakyReLU(0.2) /
+All 351 convolutions run on the matrix-core engine (fp16x3 split precision by
+default, exact fp32 with ``precision="f32"``) with bias / LeakyReLU(0.2) /
 ``x5*0.2 + x`` / ``out*0.2 + x`` fused into the epilogues.  A dense block's
 ``torch.cat((x, x1, ..))`` is one 192-channel NHWC buffer: each conv reads the
 leading channels and appends 32 more, so nothing is ever copied; the two nearest
-x2 upsamples are folded into the following conv's operand fetch.
+x2 upsamples are folded into the following conv's operand fetch.  The x4-resolution
+tail (upconv2 -> HRconv -> conv_last) is computed in bands of output rows, each
+band recomputing the few rows of context its 3x3 convs need, so its 64-channel
+intermediates are band-sized scratch buffers instead of two 4 GiB tensors.
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 import torch
@@ -39,10 +45,13 @@ class RRDBNet:
         with torch.cuda.device(device), E.default_precision(precision):
             pc = lambda k, prec=None: E.pack_conv(sd[k + ".weight"], sd[k + ".bias"], None, 1, 1, device,
                                                   precision=prec)
-            p = {k: pc(k) for k in ("conv_first", "trunk_conv", "upconv1", "upconv2")}
-            # the x4-resolution tail reads a 64-channel tensor of 4 GiB at 1024^2 inputs: beyond the
-            # 32-bit buffer addressing of the f16x3 kernel, so these two always use the fp32 kernel
-            p["HRconv"], p["conv_last"] = pc("HRconv", "f32"), pc("conv_last", "f32")
+            p = {k: pc(k) for k in ("conv_first", "trunk_conv", "upconv1", "upconv2", "HRconv")}
+            # conv_last has 3 output channels; the split32 epilogue stores 8-channel groups, so its filter is
+            # zero-padded to 8 outputs (channels 3..7 of the band scratch are zeros nobody reads)
+            wl, bl = sd["conv_last.weight"], sd["conv_last.bias"]
+            wl8 = np.zeros((8,) + tuple(wl.shape[1:]), np.float32); wl8[:3] = torch.as_tensor(wl).float().numpy()
+            bl8 = np.zeros((8,), np.float32); bl8[:3] = torch.as_tensor(bl).float().numpy()
+            p["conv_last"] = E.pack_conv(wl8, bl8, None, 1, 1, device)
             p["trunk"] = [[[pc(f"RRDB_trunk.{t}.RDB{r}.conv{c}") for c in range(1, 6)] for r in (1, 2, 3)]
                           for t in range(self.NUM_BLOCKS)]
             self._p = p
@@ -71,10 +80,36 @@ class RRDBNet:
         fea = E.conv(p["trunk_conv"], bufs[0].slice(0, 64), res1=fea0, res1_pre=False, out_fmt=f)
         del bufs
         fea = E.conv(p["upconv1"], fea, act_slope=0.2, in_up2=True, out_fmt=f)
-        fea = E.conv(p["upconv2"], fea, act_slope=0.2, in_up2=True)     # fp32 out: the x4 tail runs the fp32 kernel
-        fea = E.conv(p["HRconv"], fea, act_slope=0.2)
-        out = E.Act.empty(n, 4 * h, 4 * w, 4, dev)
-        E.conv(p["conv_last"], fea, out.slice(0, 3))
+        return self._tail(fea, f)
+
+    TAIL_BAND = int(os.environ.get("FCP_RRDB_TAIL_BAND", "256"))    # x4-resolution output rows per band
+
+    def _tail(self, fea2: E.Act, f: int) -> E.Act:
+        """upconv2(up2(fea2)) -> HRconv -> conv_last over bands of x4-resolution rows (rrdb.py:72-74 of the reference).
+
+        A band [r0, r1) of output rows needs HRconv rows [r0-1, r1+1), upconv2 rows [r0-2, r1+2) and the x2-resolution
+        rows [(r0-3)/2, ..): every band runs the three convs on a view with >= 4 rows of margin on interior edges, where
+        the zero padding a conv applies at the edge of its VIEW only spoils rows that are thrown away; at the true image
+        border the view ends there and the zero padding is the right one.  Rows [r0, r1) of the last conv are copied out."""
+        p = self._p
+        n, h2, w2, dev = fea2.n, fea2.h, fea2.w, fea2.buf.device
+        h4, w4, band = 2 * h2, 2 * w2, max(8, self.TAIL_BAND & ~1)
+        out = E.Act.empty(n, h4, w4, 4, dev)
+        rows_max = min(h4, band + 10)
+        sa = torch.empty((1, rows_max, w4, 64), dtype=torch.float32, device=dev)
+        sb = torch.empty((1, rows_max, w4, 64), dtype=torch.float32, device=dev)
+        sc = torch.empty((1, rows_max, w4, 8), dtype=torch.float32, device=dev)
+        for i in range(n):
+            for r0 in range(0, h4, band):
+                r1 = min(h4, r0 + band)
+                a, b = max(0, r0 // 2 - 2), min(h2, (r1 + 1) // 2 + 2)
+                rows = 2 * (b - a)
+                src = E.Act(fea2.buf[i:i + 1, a:b], fea2.c0, fea2.c, fea2.fmt)
+                ta, tb, tc = (E.Act(t[:, :rows], fmt=ff) for t, ff in ((sa, f), (sb, f), (sc, 0)))
+                E.conv(p["upconv2"], src, ta, act_slope=0.2, in_up2=True)
+                E.conv(p["HRconv"], ta, tb, act_slope=0.2)
+                E.conv(p["conv_last"], tb, tc)
+                out.buf[i, r0:r1, :, :3].copy_(sc[0, r0 - 2 * a:r1 - 2 * a, :, :3])
         return out
 
     def enhance_u8(self, images_u8: torch.Tensor, which) -> torch.Tensor:
