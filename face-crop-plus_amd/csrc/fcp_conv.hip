@@ -387,6 +387,8 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
       k.grid_n = 1;
       const unsigned long out_bytes = (unsigned long)M * d->out_ld * 4ul;
       FCP_REQUIRE(out_bytes < 0xFFFFFFF0ul, "conv(halo): the output view must span less than 4 GiB");
+      FCP_REQUIRE(d->wscale != nullptr && ((uintptr_t)d->wscale & 15) == 0 && ((uintptr_t)d->bias & 15) == 0,
+                  "conv(halo): wscale / bias must be 16-byte aligned");
       k.in2_bytes = (unsigned)out_bytes;                // halo launches take no second source: the field carries |out|
       k.w_bytes = (unsigned)((unsigned long)fcp_cdiv(d->cout, 128) * 128ul * k.wrow * 4ul);
       return launch_f16x3_halo(k, s);

@@ -6,13 +6,18 @@
 // operand-feed limit.  Here a workgroup owns an 8 x 32 patch of output pixels and stages, per 32-channel
 // slice, the (8+2) x (32+2) halo patch ONCE; the nine taps read it at shifted row indices.
 //
-//  * 4 waves, one workgroup per CU; wave w computes image rows 2w, 2w+1 of the patch (two 32x32 MFMA
-//    tiles) x 32 filters per pass; cout = 64 runs two passes per slice over the same halo patch.
+//  * 8 waves, one workgroup per CU: four COMPUTE waves (wave w: image rows 2w, 2w+1 of the patch = two 32x32 MFMA
+//    tiles x 32 filters per pass; cout = 64 runs two passes per slice over the same halo patch) and four LOADER
+//    waves that issue every LDS-DMA.  An LDS-DMA instruction occupies its wave until the vector-memory path has
+//    taken all 64 lanes' requests (~90 cycles each in a burst of 80 per block: cycle probes put 25 % of the
+//    kernel there when the compute waves issued them); a loader wave can sit in that queue while the compute
+//    wave of the same SIMD keeps the matrix pipe fed.
 //  * LDS: two halo stages [344][128 B] + two filter buffers [9 taps][32][128 B] = 158 KiB.  A "block" =
-//    (slice, pass) = 9 taps = 108 MFMAs per wave, ONE barrier per block; the DMA of the next block's filter
-//    buffer / next slice's halo stage is issued a whole block ahead.
-//  * The nine taps are unrolled: a tap is 12 ds_read_b128 (the NEXT tap's fragments, written into the registers of
-//    the k-half whose six MFMAs have just been issued) + 6 address XORs + 12 MFMAs, with no scalar bookkeeping or
+//    (slice, pass) = 9 taps = 108 MFMAs per wave, ONE barrier per block: the compute waves arrive when they have
+//    read the block's last fragments (its buffers are dead), the loader waves when the NEXT block's operands
+//    have landed (vmcnt(0)); behind it the loaders refill the dead buffers with the block two ahead.
+//  * The nine taps are unrolled: a tap is 12 MFMAs with the 12 ds_read_b128 of the NEXT tap's fragments between
+//    them (each read follows the last MFMA that takes the register's old contents), with no scalar bookkeeping or
 //    branch in between.  (The first version kept tap / slice / stage as run-time state: rocprof showed 26 % matrix-pipe
 //    utilisation, ~1000 idle cycles per tap in compare / select / branch chains between the MFMA groups.)
 //    Fragment addresses: for a halo row the four 16-byte chunks a lane needs (hi / lo x k-half) differ only in
@@ -69,7 +74,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int TN>   // 32-filter passes per slice: cout <= 32 * TN
-__global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
+__global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -82,20 +87,124 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
   const int per_x = (ntiles + 7) / 8;
   const int xcd = bid & 7, slot = bid >> 3, slots = (nb + 7 - xcd) / 8;   // workgroups of this XCD: slot = 0..slots-1
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lrow = tid >> 3;                          // 0..31 (+32 i)
-  const int csrc = (tid & 7) ^ swz(lrow);             // rows differ by multiples of 32: one swizzle per thread
-  const int xl = lane & 31, half = lane >> 5;
+  const int lane = threadIdx.x & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool loader = wave8 >= 4;                     // waves 4..7 issue the LDS-DMA, waves 0..3 compute
+  const int wave_u = wave8 & 3;
+  const int tid = threadIdx.x & 255;                  // index within the role
   const int nslices = p.ctiles;
   const int nblocks = nslices * TN;
 
-  __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
-  // filter row n = lrow (+ 32 per pass): the 9 taps of one channel slice are contiguous (9 x 128 B)
-  const unsigned wbase = (unsigned)((lrow * p.wrow) * 4 + csrc * 16);
+  // ---- the workgroup's tiles form ONE stream of blocks: a block's filter buffer is refilled two blocks ahead and a
+  //      slice's halo stage two slices ahead ACROSS tile boundaries, so a new tile starts with its operands in LDS.
+  //      Both roles walk the same stream and meet at the same barriers.
+  int it = slot;
+  if (it >= per_x || xcd * per_x + it >= ntiles) return;
 
+  if (loader) {
+    // =================================================================== loader waves
+    const int lrow = tid >> 3;                          // 0..31 (+32 i)
+    const int csrc = (tid & 7) ^ swz(lrow);             // rows differ by multiples of 32: one swizzle per thread
+    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    // filter row n = lrow (+ 32 per pass): the 9 taps of one channel slice are contiguous (9 x 128 B)
+    const unsigned wbase = (unsigned)((lrow * p.wrow) * 4 + csrc * 16);
+    unsigned abase[A_LD];
+    int hyx[A_LD];                                       // halo row lrow + 32 i -> (hy << 8 | hx), or -1 past the patch
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int hr = lrow + 32 * i;
+      const int hy = hr / HW_, hx = hr - hy * HW_;
+      hyx[i] = hr < (TH + 2) * HW_ ? (hy << 8 | hx) : -1;
+    }
+    auto tile_setup = [&](int tile) {
+      const int tx = tile % tiles_x;
+      const int ty = (tile / tiles_x) % tiles_y;
+      const int ni = tile / (tiles_x * tiles_y);
+      const int y0 = ty * TH, x0 = tx * TW;
+      // halo row (hy, hx) -> input pixel (y0 - 1 + hy, x0 - 1 + hx)
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const int y = y0 - 1 + (hyx[i] >> 8), x = x0 - 1 + (hyx[i] & 255);
+        const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)p.in_h && (unsigned)x < (unsigned)p.in_w;
+        abase[i] = ok ? ((unsigned)((ni * p.in_h + y) * p.in_w + x) * (unsigned)p.in_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
+      }
+    };
+    auto dma_halo = [&](int cs, int stage) {             // 11 (waves 0..2) / 10 (wave 3) instructions
+      char* a = lds + stage * A_BYTES + wave_u * 8 * ROWB;
+#pragma unroll
+      for (int i = 0; i < A_LD - 1; ++i) {
+        const unsigned ro = abase[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * i * ROWB), 16,
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(cs * 128)), 0, 0, 0);
+      }
+      if (wave_u < 3) {   // rows 320..343
+        const unsigned ro = abase[A_LD - 1];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * (A_LD - 1) * ROWB), 16,
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(cs * 128)), 0, 0, 0);
+      }
+    };
+    auto dma_filter = [&](int blk, int buf) {            // block = slice * TN + pass; 9 instructions
+      const int cs = blk / TN, pass = blk - cs * TN;
+      char* b = lds + B_OFF + buf * B_BYTES + wave_u * 8 * ROWB;
+      const unsigned wo = wbase + (unsigned)(pass * 32 * p.wrow * 4 + cs * 9 * 128);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 32 * t * ROWB), 16,
+                                                 (int)(wo + (unsigned)(t * 128)), 0, 0, 0);
+    };
+
+    tile_setup(xcd * per_x + it);
+    dma_halo(0, 0);
+    dma_filter(0, 0);
+    dma_halo(1, 1);                                       // nslices >= 2 (launcher)
+    dma_filter(1, 1);
+    int blk = 0;
+    unsigned bbuf = 0, astage = 0;                        // filter buffer of the current block, halo stage of the current slice
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // P: blocks 0 and 1 are in LDS
+    for (;;) {
+      const bool new_slice = TN == 1 || (blk & 1) != 0;              // the next block starts the next channel slice
+      const int cs = blk / TN;
+      const bool last_of_tile = blk == nblocks - 1;
+      const int nit = it + slots, ntile = xcd * per_x + nit;
+      const bool more = nit < per_x && ntile < ntiles;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the NEXT block's operands have landed
+      __builtin_amdgcn_s_barrier();                                  // X: ... and this block's buffers are dead
+      // refill what just died with the operands of the block two ahead in the stream
+      bool halo_delayed = false;
+      const int b2 = blk + 2;
+      if (b2 < nblocks) dma_filter(b2, (int)bbuf);
+      else if (more) dma_filter(b2 - nblocks, (int)bbuf);
+      if (new_slice) {
+        const int s2 = cs + 2;
+        if (s2 < nslices) dma_halo(s2, (int)astage);
+        else if (more) {
+          if (s2 == nslices) {                                       // next tile's first slice: its addresses replace this tile's
+            tile_setup(ntile);
+            dma_halo(0, (int)astage);
+          } else {
+            halo_delayed = true;                                     // next tile's second slice: the freed stage hosts the epilogue first
+          }
+        }
+      }
+      const unsigned freed = astage;
+      bbuf ^= 1u;
+      if (new_slice) astage ^= 1u;
+      ++blk;
+      if (new_slice && last_of_tile) {
+#pragma unroll
+        for (int n = 0; n < 2 * TN; ++n) __builtin_amdgcn_s_barrier();   // the compute waves' epilogue (two barriers per pass)
+        if (!more) return;
+        if (halo_delayed) dma_halo(1, (int)freed);
+        it = nit;
+        blk = 0;
+      }
+    }
+  }
+
+  // ===================================================================== compute waves
+  const int xl = lane & 31, half = lane >> 5;
   // ---- fragment addressing (per lane, tile independent)
   // halo rows read by this lane: hr = (2 w + d) * 34 + xl + kw, d = i + kh in 0..3, kw in 0..2.  aaddr[d][kw] is
   // the LDS address (stage 0) of chunk (half ^ swz(hr)); the chunks (2 + half), (4 + half), (6 + half) ^ swz(hr)
@@ -111,57 +220,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
   // filter fragments: row xl of tap t at B_OFF + buf * B_BYTES + t * 4096 + xl * 128, chunk c ^ swz(xl)
   const unsigned baddr0 = lds0 + (unsigned)(B_OFF + xl * ROWB + ((half ^ swz(xl)) << 4));
 
-  f16x8 fah[2][2], fal[2][2], fbh[2], fbl[2];   // [tile | k-half][k-half]: ONE set, refilled half by half (see tap_step)
+  f16x8 fah[2][2], fal[2][2], fbh[2], fbl[2];   // [tile | k-half][k-half]: ONE set, refilled register by register (see tap_step)
 
-  // ---- per-tile state
-  unsigned abase[A_LD];
-  int hyx[A_LD];                                       // halo row lrow + 32 i -> (hy << 8 | hx), or -1 past the patch
-#pragma unroll
-  for (int i = 0; i < A_LD; ++i) {
-    const int hr = lrow + 32 * i;
-    const int hy = hr / HW_, hx = hr - hy * HW_;
-    hyx[i] = hr < (TH + 2) * HW_ ? (hy << 8 | hx) : -1;
-  }
-  int ni = 0, y0 = 0, x0 = 0;
-  auto tile_setup = [&](int tile) {
-    const int tx = tile % tiles_x;
-    const int ty = (tile / tiles_x) % tiles_y;
-    ni = tile / (tiles_x * tiles_y);
-    y0 = ty * TH; x0 = tx * TW;
-    // halo row (hy, hx) -> input pixel (y0 - 1 + hy, x0 - 1 + hx)
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      const int y = y0 - 1 + (hyx[i] >> 8), x = x0 - 1 + (hyx[i] & 255);
-      const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)p.in_h && (unsigned)x < (unsigned)p.in_w;
-      abase[i] = ok ? ((unsigned)((ni * p.in_h + y) * p.in_w + x) * (unsigned)p.in_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
-    }
-  };
-  auto dma_halo = [&](int cs, int stage) {             // 11 (waves 0..2) / 10 (wave 3) instructions
-    char* a = lds + stage * A_BYTES + wave_u * 8 * ROWB;
-#pragma unroll
-    for (int i = 0; i < A_LD - 1; ++i) {
-      const unsigned ro = abase[i];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * i * ROWB), 16,
-                                               (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(cs * 128)), 0, 0, 0);
-    }
-    if (wave_u < 3) {   // rows 320..343
-      const unsigned ro = abase[A_LD - 1];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * (A_LD - 1) * ROWB), 16,
-                                               (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(cs * 128)), 0, 0, 0);
-    }
-  };
-  auto dma_filter = [&](int blk, int buf) {            // block = slice * TN + pass; 9 instructions
-    const int cs = blk / TN, pass = blk - cs * TN;
-    char* b = lds + B_OFF + buf * B_BYTES + wave_u * 8 * ROWB;
-    const unsigned wo = wbase + (unsigned)(pass * 32 * p.wrow * 4 + cs * 9 * 128);
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 32 * t * ROWB), 16,
-                                               (int)(wo + (unsigned)(t * 128)), 0, 0, 0);
-  };
-
-  // fragment `idx` (0..11, in the order the MFMAs consume them: k-half 0 {bh, al0, al1, bl, ah0, ah1}, then k-half 1) of
-  // tap TAP from halo stage offset `aoff` / filter buffer offset `boff`
+  // fragment `idx` (0..11: k-half 0 {bh, al0, al1, bl, ah0, ah1}, then k-half 1) of tap TAP from halo stage offset
+  // `aoff` / filter buffer offset `boff`
   auto read_one = [&](auto tap_c, auto idx_c, unsigned aoff, unsigned boff) {
     constexpr int tap = decltype(tap_c)::value, idx = decltype(idx_c)::value;
     constexpr int kh = tap / 3, kw = tap % 3;
@@ -177,34 +239,18 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
     }
   };
 
-  // epilogue constants of this thread's 8 channels per pass; output through a buffer resource (out-of-range
-  // pixels get offset 0xFFFFFFFF: the hardware drops the store, no divergent branch around it)
-  float bias8[TN][8], ws8[TN][8];
-#pragma unroll
-  for (int n = 0; n < TN; ++n)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = n * 32 + (tid & 3) * 8 + e;
-      bias8[n][e] = (p.bias != nullptr && c < p.cout) ? p.bias[c] : 0.f;
-      ws8[n][e] = c < p.cout ? p.wscale[c] : 0.f;
-    }
+  // output through a buffer resource (out-of-range pixels get offset 0xFFFFFFFF: the hardware drops the store, no
+  // divergent branch around it)
   __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.in2_bytes, 0x00020000);   // in2_bytes: size of `out` (halo launches)
 
-  // ---- the workgroup's tiles form ONE stream of blocks: a block's filter buffer is refilled two blocks ahead and a
-  //      slice's halo stage two slices ahead ACROSS tile boundaries, so a new tile starts with its operands in LDS
-  //      (no start-of-tile burst in which all 256 workgroups ask HBM for 160 KiB at once and wait for it).
-  int it = slot;
-  if (it >= per_x || xcd * per_x + it >= ntiles) return;
-  tile_setup(xcd * per_x + it);
-  int e_ni = ni, e_y0 = y0, e_x0 = x0;                 // coordinates of the tile being computed (tile_setup runs ahead)
-  dma_halo(0, 0);
-  dma_filter(0, 0);
-  dma_halo(1, 1);                                       // nslices >= 2 (launcher)
-  dma_filter(1, 1);
-  if (wave_u < 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + 9) : "memory");       // halo(1) [11 | 10 per wave] + filter(1) [9] may fly
-  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD - 1 + 9) : "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
+  int e_ni = 0, e_y0 = 0, e_x0 = 0;                     // coordinates of the tile being computed
+  auto tile_coords = [&](int tile) {
+    const int tx = tile % tiles_x;
+    const int ty = (tile / tiles_x) % tiles_y;
+    e_ni = tile / (tiles_x * tiles_y);
+    e_y0 = ty * TH; e_x0 = tx * TW;
+  };
+  tile_coords(xcd * per_x + it);
 
   f32x16 acc[TN][2];
   auto zero_acc = [&]() {
@@ -217,13 +263,17 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
   };
   zero_acc();
 
+  __builtin_amdgcn_s_barrier();                         // P: blocks 0 and 1 are in LDS
+  __builtin_amdgcn_sched_barrier(0);
+
   // fragments of (block 0, tap 0)
   static_for<0, 12>([&](auto ic) { read_one(std::integral_constant<int, 0>{}, ic, 0u, 0u); });
 
-  // One tap = 12 MFMAs: six on the k-half-0 fragments, six on the k-half-1 fragments.  There is ONE fragment set: as soon
-  // as the six MFMAs of a k-half have been issued its registers are refilled with the NEXT tap's fragments of that
-  // k-half (the matrix pipe reads its A / B operands when the instruction issues; the LDS data lands tens of cycles
-  // later), which then have six MFMAs (~190 cycles) to arrive.  lgkmcnt(6): the older group of six reads is complete.
+  // One tap = 12 MFMAs: six on the k-half-0 fragments, six on the k-half-1 fragments.  There is ONE fragment set: the
+  // next tap's read of a fragment follows the LAST MFMA that takes the register's old contents (the matrix pipe has its
+  // A / B operands long before the LDS data lands), one or two reads per MFMA, so a wave's LDS requests are spread over
+  // the group and land while the other k-half's six MFMAs (~190 cycles) run.  lgkmcnt(6): the older group of six
+  // reads is complete.
   auto tap_step = [&](auto tap_c, auto pass_c, unsigned aoff_n, unsigned boff_n, bool prefetch) {
     constexpr int tap = decltype(tap_c)::value, pass = decltype(pass_c)::value;
     constexpr int ntap = (tap + 1) % 9;
@@ -232,18 +282,20 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
       if (s == 0 || prefetch) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[pass][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i][s], fbh[s], acc[pass][i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[pass][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i][s], fbl[s], acc[pass][i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[pass][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i][s], fbh[s], acc[pass][i], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (prefetch)
-        static_for<0, 6>([&](auto rc) {
-          read_one(std::integral_constant<int, ntap>{}, std::integral_constant<int, 6 * s + decltype(rc)::value>{}, aoff_n, boff_n);
-        });
-      __builtin_amdgcn_sched_barrier(0);
+      auto rd = [&](auto rc) {
+        if (prefetch) read_one(std::integral_constant<int, ntap>{}, std::integral_constant<int, 6 * s + decltype(rc)::value>{}, aoff_n, boff_n);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto mm = [&](int i, const f16x8& a, const f16x8& b) {
+        acc[pass][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[pass][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      mm(0, fal[0][s], fbh[s]); rd(std::integral_constant<int, 1>{});
+      mm(1, fal[1][s], fbh[s]); rd(std::integral_constant<int, 2>{});
+      mm(0, fah[0][s], fbl[s]);
+      mm(1, fah[1][s], fbl[s]); rd(std::integral_constant<int, 3>{});
+      mm(0, fah[0][s], fbh[s]); rd(std::integral_constant<int, 4>{});
+      mm(1, fah[1][s], fbh[s]); rd(std::integral_constant<int, 5>{}); rd(std::integral_constant<int, 0>{});
     });
   };
 
@@ -252,6 +304,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
     const unsigned cs0 = lds0 + (unsigned)(stage * A_BYTES);
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
+      // this thread's 8 channels of the pass: constants requested first, consumed after the staging barrier
+      const int ccol = n * 32 + (tid & 3) * 8;
+      const bool cvalid = ccol < p.cout;
+      f32x4 b8[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, w8[2] = {b8[0], b8[0]};
+      if (cvalid) {                                                  // cout % 8 == 0 (launcher): whole groups of 8
+        if (p.bias != nullptr) { b8[0] = *reinterpret_cast<const f32x4*>(p.bias + ccol); b8[1] = *reinterpret_cast<const f32x4*>(p.bias + ccol + 4); }
+        w8[0] = *reinterpret_cast<const f32x4*>(p.wscale + ccol); w8[1] = *reinterpret_cast<const f32x4*>(p.wscale + ccol + 4);
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -262,51 +322,52 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      const int ccol = n * 32 + (tid & 3) * 8;
-      const bool cvalid = ccol < p.cout;
-      f32x4 va[4], vb[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const unsigned ra = cs0 + (unsigned)((((tid >> 2) + 64 * g) * 32 + (tid & 3) * 8) * 4);
-        va[g] = lds_read128f(ra);
-        vb[g] = lds_read128f(ra + 16);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+      for (int gp = 0; gp < 2; ++gp) {
+        f32x4 va[2], vb[2];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = (tid >> 2) + 64 * g;
-        const int y = e_y0 + (row >> 5), x = e_x0 + (row & 31);
-        const bool ok = cvalid && y < p.out_h && x < p.out_w;
-        const long m = ok ? ((long)e_ni * p.out_h + y) * p.out_w + x : 0;
-        float v[8] = {va[g][0], va[g][1], va[g][2], va[g][3], vb[g][0], vb[g][1], vb[g][2], vb[g][3]};
-        float r1[8], r2[8];
-        if (p.res1 != nullptr) load8(p.res1, m, p.res1_ld, cvalid ? ccol : 0, p.res1_fmt, r1);
-        if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, cvalid ? ccol : 0, p.res2_fmt, r2);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float t = v[e] * ws8[n][e] + bias8[n][e];
-          if (p.res1 != nullptr && p.res1_pre) t += r1[e];
-          t = t >= 0.f ? t : t * p.act_slope;
-          t = t * p.alpha;
-          if (p.res1 != nullptr && !p.res1_pre) t += r1[e];
-          if (p.res2 != nullptr) t = t * p.alpha2 + r2[e];
-          v[e] = t;
+        for (int g = 0; g < 2; ++g) {
+          const unsigned ra = cs0 + (unsigned)((((tid >> 2) + 64 * (2 * gp + g)) * 32 + (tid & 3) * 8) * 4);
+          va[g] = lds_read128f(ra);
+          vb[g] = lds_read128f(ra + 16);
         }
-        u32x4_t s0, s1;
-        unsigned o0, o1;
-        if (p.out_fmt == 1) {
-          split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, s0, s1);
-          o0 = (unsigned)(m * p.out_ld * 4 + split_chan_off(ccol));
-          o1 = o0 + 64u;
-        } else {
-          s0 = __builtin_bit_cast(u32x4_t, f32x4{v[0], v[1], v[2], v[3]});
-          s1 = __builtin_bit_cast(u32x4_t, f32x4{v[4], v[5], v[6], v[7]});
-          o0 = (unsigned)((m * p.out_ld + ccol) * 4);
-          o1 = o0 + 16u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int row = (tid >> 2) + 64 * (2 * gp + g);
+          const int y = e_y0 + (row >> 5), x = e_x0 + (row & 31);
+          const bool ok = cvalid && y < p.out_h && x < p.out_w;
+          const long m = ok ? ((long)e_ni * p.out_h + y) * p.out_w + x : 0;
+          float v[8] = {va[g][0], va[g][1], va[g][2], va[g][3], vb[g][0], vb[g][1], vb[g][2], vb[g][3]};
+          float r1[8], r2[8];
+          if (p.res1 != nullptr) load8(p.res1, m, p.res1_ld, cvalid ? ccol : 0, p.res1_fmt, r1);
+          if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, cvalid ? ccol : 0, p.res2_fmt, r2);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = v[e] * w8[e >> 2][e & 3] + b8[e >> 2][e & 3];
+            if (p.res1 != nullptr && p.res1_pre) t += r1[e];
+            t = t >= 0.f ? t : t * p.act_slope;
+            t = t * p.alpha;
+            if (p.res1 != nullptr && !p.res1_pre) t += r1[e];
+            if (p.res2 != nullptr) t = t * p.alpha2 + r2[e];
+            v[e] = t;
+          }
+          u32x4_t s0, s1;
+          unsigned o0, o1;
+          if (p.out_fmt == 1) {
+            split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, s0, s1);
+            o0 = (unsigned)(m * p.out_ld * 4 + split_chan_off(ccol));
+            o1 = o0 + 64u;
+          } else {
+            s0 = __builtin_bit_cast(u32x4_t, f32x4{v[0], v[1], v[2], v[3]});
+            s1 = __builtin_bit_cast(u32x4_t, f32x4{v[4], v[5], v[6], v[7]});
+            o0 = (unsigned)((m * p.out_ld + ccol) * 4);
+            o1 = o0 + 16u;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(s0, rs_out, ok ? o0 : 0xFFFFFFFFu, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(s1, rs_out, ok ? o1 : 0xFFFFFFFFu, 0, 0);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(s0, rs_out, ok ? o0 : 0xFFFFFFFFu, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(s1, rs_out, ok ? o1 : 0xFFFFFFFFu, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();                                 // the fp32 tile may be rewritten / its stage refilled
@@ -314,44 +375,33 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
     }
   };
 
+#ifdef FCP_HALO_PROBE   // cycle attribution of workgroup 0 / each compute wave's lane 0 (experiment builds): printed at exit
+  unsigned long long pc[5] = {0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+  const unsigned long long pstart = pt;
+#define PROBE(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); pc[k] += t_ - pt; pt = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PROBE(k) do { } while (0)
+#endif
   // ---- main loop over the stream of blocks (slice, pass): nine unrolled taps each
   int blk = 0;                                          // block index inside the current tile
   unsigned bbuf = 0, astage = 0;                        // filter buffer of the current block, halo stage of the current slice
   auto run_block = [&](auto pass_c) -> bool {           // true: the workgroup is done
     constexpr int pass = decltype(pass_c)::value;
     constexpr bool new_slice = pass == TN - 1;                       // the next block starts the next channel slice
-    const int cs = blk / TN;
     const unsigned aoff = astage * (unsigned)A_BYTES, boff = bbuf * (unsigned)B_BYTES;
     const bool last_of_tile = blk == nblocks - 1;
     const int nit = it + slots, ntile = xcd * per_x + nit;
     const bool more = nit < per_x && ntile < ntiles;
+    PROBE(4);
     static_for<0, 8>([&](auto tc) { tap_step(tc, pass_c, aoff, boff, true); });
+    PROBE(0);
     // tap 8's fragments are (about to be) in registers: the block's buffer (and, after the last pass, the slice's
-    // stage) is dead for this wave; the next block's operands were requested a block ago
+    // stage) is dead for this wave; the loaders arrive when the next block's operands are in LDS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PROBE(1);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // refill what just died with the operands of the block two ahead in the stream
-    bool halo_delayed = false;
-    {
-      const int b2 = blk + 2;
-      if (b2 < nblocks) dma_filter(b2, (int)bbuf);
-      else if (more) dma_filter(b2 - nblocks, (int)bbuf);
-      if constexpr (new_slice) {
-        const int s2 = cs + 2;
-        if (s2 < nslices) dma_halo(s2, (int)astage);
-        else if (more) {
-          if (s2 == nslices) {                                       // next tile's first slice: its addresses replace this tile's
-            tile_setup(ntile);
-            dma_halo(0, (int)astage);
-          } else {
-            halo_delayed = true;                                     // next tile's second slice: the freed stage hosts the epilogue first
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    PROBE(2);
     const unsigned aoff_next = new_slice ? (astage ^ 1u) * (unsigned)A_BYTES : aoff;
     const unsigned boff_next = (bbuf ^ 1u) * (unsigned)B_BYTES;
     tap_step(std::integral_constant<int, 8>{}, pass_c, aoff_next, boff_next, !(last_of_tile && !more));
@@ -362,12 +412,18 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_f16x3(const ConvK p) {
     if constexpr (new_slice) {
       if (last_of_tile) {
         __builtin_amdgcn_sched_barrier(0);
+        PROBE(4);
         epilogue((int)freed);
+        PROBE(3);
+#ifdef FCP_HALO_PROBE
+        if (!more && blockIdx.x == 0 && lane == 0)
+          printf("wave %d: total %llu cycles; taps0-7 %llu, lgkm wait %llu, barrier %llu, epilogue %llu, rest (tap 8) %llu\n", wave_u,
+                 __builtin_readcyclecounter() - pstart, pc[0], pc[1], pc[2], pc[3], pc[4]);
+#endif
         if (!more) return true;
-        if (halo_delayed) dma_halo(1, (int)freed);
         it = nit;
         blk = 0;
-        e_ni = ni; e_y0 = y0; e_x0 = x0;
+        tile_coords(ntile);
         zero_acc();
       }
     }
@@ -402,10 +458,10 @@ int launch_f16x3_halo(const ConvK& k, hipStream_t s) {
   const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
   if (k.cout <= 32) {
     FCP_LDS_OPT_IN(&conv3x3_halo_f16x3<1>, lds);
-    hipLaunchKernelGGL(conv3x3_halo_f16x3<1>, dim3(grid), dim3(256), lds, s, k);
+    hipLaunchKernelGGL(conv3x3_halo_f16x3<1>, dim3(grid), dim3(512), lds, s, k);
   } else {
     FCP_LDS_OPT_IN(&conv3x3_halo_f16x3<2>, lds);
-    hipLaunchKernelGGL(conv3x3_halo_f16x3<2>, dim3(grid), dim3(256), lds, s, k);
+    hipLaunchKernelGGL(conv3x3_halo_f16x3<2>, dim3(grid), dim3(512), lds, s, k);
   }
   FCP_LAUNCH_OK();
   return 0;
