@@ -193,8 +193,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
       if (new_slice) astage ^= 1u;
       ++blk;
       if (new_slice && last_of_tile) {
-#pragma unroll
-        for (int n = 0; n < 2 * TN; ++n) __builtin_amdgcn_s_barrier();   // the compute waves' epilogue (two barriers per pass)
+        __builtin_amdgcn_s_barrier();                                  // the compute waves have read the finished tile back from `freed`
         if (!more) return;
         if (halo_delayed) dma_halo(1, (int)freed);
         it = nit;
@@ -274,16 +273,15 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
   // A / B operands long before the LDS data lands), one or two reads per MFMA, so a wave's LDS requests are spread over
   // the group and land while the other k-half's six MFMAs (~190 cycles) run.  lgkmcnt(6): the older group of six
   // reads is complete.
-  auto tap_step = [&](auto tap_c, auto pass_c, unsigned aoff_n, unsigned boff_n, bool prefetch) {
+  auto tap_step = [&](auto tap_c, auto pass_c, unsigned aoff_n, unsigned boff_n) {
     constexpr int tap = decltype(tap_c)::value, pass = decltype(pass_c)::value;
     constexpr int ntap = (tap + 1) % 9;
     static_for<0, 2>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
-      if (s == 0 || prefetch) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       auto rd = [&](auto rc) {
-        if (prefetch) read_one(std::integral_constant<int, ntap>{}, std::integral_constant<int, 6 * s + decltype(rc)::value>{}, aoff_n, boff_n);
+        read_one(std::integral_constant<int, ntap>{}, std::integral_constant<int, 6 * s + decltype(rc)::value>{}, aoff_n, boff_n);
         __builtin_amdgcn_sched_barrier(0);
       };
       auto mm = [&](int i, const f16x8& a, const f16x8& b) {
@@ -301,11 +299,15 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
 
   // epilogue of the finished tile through a [256 pixels][32 channels] fp32 tile in halo stage `stage` (just freed)
   auto epilogue = [&](int stage) {
-    const unsigned cs0 = lds0 + (unsigned)(stage * A_BYTES);
+    // A wave stages, reads back and stores only ITS OWN 64 pixels (LDS accesses of one wave execute in order), so the
+    // passes need no barrier between the waves; the single barrier at the end tells the loaders that the stage may
+    // be refilled.
+    const unsigned cs0 = lds0 + (unsigned)(stage * A_BYTES + wave_u * 64 * 128);
+    const int eq = lane & 3, er = lane >> 2;                       // 8-channel group, row (+ 16 g) within the wave's 64
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
-      // this thread's 8 channels of the pass: constants requested first, consumed after the staging barrier
-      const int ccol = n * 32 + (tid & 3) * 8;
+      // this thread's 8 channels of the pass: constants requested first, consumed after the staging
+      const int ccol = n * 32 + eq * 8;
       const bool cvalid = ccol < p.cout;
       f32x4 b8[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, w8[2] = {b8[0], b8[0]};
       if (cvalid) {                                                  // cout % 8 == 0 (launcher): whole groups of 8
@@ -316,18 +318,16 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
-          const int row = (2 * wave_u + i) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+          const int row = i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
           lds_write32(cs0 + (unsigned)((row * 32 + xl) * 4), acc[n][i][rr]);
         }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int gp = 0; gp < 2; ++gp) {
         f32x4 va[2], vb[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          const unsigned ra = cs0 + (unsigned)((((tid >> 2) + 64 * (2 * gp + g)) * 32 + (tid & 3) * 8) * 4);
+          const unsigned ra = cs0 + (unsigned)(((er + 16 * (2 * gp + g)) * 32 + eq * 8) * 4);
           va[g] = lds_read128f(ra);
           vb[g] = lds_read128f(ra + 16);
         }
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          const int row = (tid >> 2) + 64 * (2 * gp + g);
+          const int row = wave_u * 64 + er + 16 * (2 * gp + g);     // pixel of the 8 x 32 patch
           const int y = e_y0 + (row >> 5), x = e_x0 + (row & 31);
           const bool ok = cvalid && y < p.out_h && x < p.out_w;
           const long m = ok ? ((long)e_ni * p.out_h + y) * p.out_w + x : 0;
@@ -370,9 +370,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                                 // the fp32 tile may be rewritten / its stage refilled
-      __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_s_barrier();                                   // every wave has read its pixels back: the stage may be refilled
+    __builtin_amdgcn_sched_barrier(0);
   };
 
 #ifdef FCP_HALO_PROBE   // cycle attribution of workgroup 0 / each compute wave's lane 0 (experiment builds): printed at exit
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
     const int nit = it + slots, ntile = xcd * per_x + nit;
     const bool more = nit < per_x && ntile < ntiles;
     PROBE(4);
-    static_for<0, 8>([&](auto tc) { tap_step(tc, pass_c, aoff, boff, true); });
+    static_for<0, 8>([&](auto tc) { tap_step(tc, pass_c, aoff, boff); });
     PROBE(0);
     // tap 8's fragments are (about to be) in registers: the block's buffer (and, after the last pass, the slice's
     // stage) is dead for this wave; the loaders arrive when the next block's operands are in LDS
@@ -404,7 +404,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
     PROBE(2);
     const unsigned aoff_next = new_slice ? (astage ^ 1u) * (unsigned)A_BYTES : aoff;
     const unsigned boff_next = (bbuf ^ 1u) * (unsigned)B_BYTES;
-    tap_step(std::integral_constant<int, 8>{}, pass_c, aoff_next, boff_next, !(last_of_tile && !more));
+    // (after the workgroup's very last block the "next block" reads fetch stale LDS contents that nothing consumes:
+    //  cheaper than a branch around every read of every tap 8; the epilogue's lgkmcnt(0) retires them)
+    tap_step(std::integral_constant<int, 8>{}, pass_c, aoff_next, boff_next);
     const unsigned freed = astage;
     bbuf ^= 1u;
     if constexpr (new_slice) astage ^= 1u;
