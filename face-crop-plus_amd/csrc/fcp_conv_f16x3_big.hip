@@ -376,6 +376,12 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 
+#ifdef FCP_BIG_PROBE   // cycle attribution (experiment builds): workgroup 0, lane 0 of each wave, printed at exit
+  unsigned long long pc[4] = {0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+#define BPROBE(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); pc[k] += t_ - pt; pt = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define BPROBE(k) do { } while (0)
+#endif
   unsigned sx = 0u;                       // XOR of the stage holding slice kt
   for (int kt = 0; kt < p.ktiles; ++kt) {
     // ---- k-half 0 of slice kt on the matrix pipe, k-half 1 on its way to registers
@@ -383,23 +389,47 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     __builtin_amdgcn_sched_barrier(0);
     mfmas(SET0);
     __builtin_amdgcn_sched_barrier(0);
+    BPROBE(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's part of slice kt+1 has landed
     __builtin_amdgcn_s_barrier();                          // slice kt+1 visible; nobody reads slice kt's stage again
     __builtin_amdgcn_sched_barrier(0);
+    BPROBE(1);
     if (kt + 1 < p.ktiles) read_frags(SET0, sx ^ (unsigned)STAGE);
-    if (kt + 2 < p.ktiles) {
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- k-half 1 of slice kt, and the DMA of slice kt+2 into the stage that has just died.  An LDS-DMA instruction
+    //      holds its wave until the vector-memory path has taken the 64 requests: with all eight waves issuing their
+    //      A_LD + B_LD instructions at once (64 KiB per slice through a 64 B/clk path) cycle probes showed BOTH waves of
+    //      a SIMD stuck there for 800-1700 cycles per slice with the matrix pipe idle.  The two waves of a SIMD (w, w+4)
+    //      therefore take the two jobs in opposite order: one feeds the matrix pipe while the other sits in the queue.
+#ifdef FCP_BIG_V1
+    const bool dma_first = true;
+#else
+    const bool dma_first = wave_u >= 4;
+#endif
+    if (dma_first && kt + 2 < p.ktiles) {
       advance();
       dma_slice(kt + 2, kt & 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- k-half 1 of slice kt
+    BPROBE(2);
     mfmas(SET1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!dma_first && kt + 2 < p.ktiles) {
+      advance();
+      dma_slice(kt + 2, kt & 1);
+    }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    BPROBE(3);
     sx ^= (unsigned)STAGE;
   }
+#ifdef FCP_BIG_PROBE
+  if (blockIdx.x == 0 && lane == 0)
+    printf("wave %d: %d slices; k-half 0 (reads+mfma) %llu, wait+barrier %llu, reads+dma issue %llu, k-half 1 mfma %llu\n", wave_u, p.ktiles,
+           pc[0], pc[1], pc[2], pc[3]);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
