@@ -280,6 +280,9 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   };
   // one slice: A_LD + B_LD DMA instructions per wave, each 64 lanes x 16 B = rows 8*wave + 64*i .. +7
   auto dma_slice = [&](int kt, int stage) {
+#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 1)      // experiment builds (wrong results): no DMA after the prologue
+    if (kt >= 2) return;
+#endif
     char* a = lds + stage * STAGE + wave_u * 8 * ROWB;
     char* b = a + BMB * ROWB;
     if (c0 >= p.csplit) {                  // wave-uniform: this slice comes from the second source
@@ -292,7 +295,11 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     } else {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
+#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 4)      // activation DMA issued out of range: zero fill, no memory traffic
+        const unsigned ro = kt >= 2 ? 0xFFFFFFFFu : rowoff[i];
+#else
         const unsigned ro = rowoff[i];
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 64 * i * ROWB), 16,
                                                  (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, 0);
       }
@@ -300,7 +307,11 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 64 * i * ROWB), 16,
+#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 8)      // filter DMA out of range
+                                               (int)(kt >= 2 ? 0xFFFFFFFFu : woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
+#else
                                                (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
+#endif
   };
 
   f32x16 acc[TM][TN];
@@ -343,6 +354,13 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   constexpr std::integral_constant<int, 1> SET1{};
   auto mfmas = [&](auto set_c) {
     constexpr int set = decltype(set_c)::value;
+#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 2)      // no MFMAs (fragments and accumulators stay live)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]) : "v"(fal[set][i]), "v"(fah[set][i]), "v"(fbh[set][j]), "v"(fbl[set][j]));
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -358,6 +376,47 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][i], fbh[set][j], acc[i][j], 0, 0, 0);
+  };
+
+  // MFMAs on fragment set CS with the reads of set LS (from the stage at `stage_xor`) between them, one read per
+  // TM * TN * 3 / (2 TM + 2 TN) MFMAs: the LDS requests of the eight lockstep waves arrive spread over the phase
+  // instead of as one burst of 8 x (2 TM + 2 TN) in front of it.  (Reads past the last slice fetch stale LDS
+  // contents nobody consumes: cheaper than a branch.)
+  auto mfmas_reads = [&](auto cs_c, auto ls_c, unsigned stage_xor) {
+    constexpr int cs = decltype(cs_c)::value, ls = decltype(ls_c)::value;
+    constexpr int NM = 3 * TM * TN, NR = 2 * TM + 2 * TN;
+    static_for<0, NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int g = m / (TM * TN), i = (m % (TM * TN)) / TN, j = m % TN;
+#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 2)
+      asm volatile("" : "+v"(acc[i][j]) : "v"(fal[cs][i]), "v"(fah[cs][i]), "v"(fbh[cs][j]), "v"(fbl[cs][j]));
+#else
+      if constexpr (g == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[cs][i], fbh[cs][j], acc[i][j], 0, 0, 0);
+      else if constexpr (g == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[cs][i], fbl[cs][j], acc[i][j], 0, 0, 0);
+      else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[cs][i], fbh[cs][j], acc[i][j], 0, 0, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      // read r is issued after MFMA floor((r + 1) * NM / NR) - 1
+      static_for<0, NR>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (((r + 1) * NM) / NR - 1 == m
+#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 16)     // no fragment reads in the loop
+                      && false
+#endif
+        ) {
+          if constexpr (r < 2 * TM) {
+            constexpr int ii = r / 2;
+            if constexpr (r % 2 == 0) fah[ls][ii] = lds_read128<ii * 32 * ROWB>(aH[ls] ^ stage_xor);
+            else fal[ls][ii] = lds_read128<ii * 32 * ROWB>(aL[ls] ^ stage_xor);
+          } else {
+            constexpr int jj = (r - 2 * TM) / 2;
+            if constexpr (r % 2 == 0) fbh[ls][jj] = lds_read128<jj * 32 * ROWB>(bH[ls] ^ stage_xor);
+            else fbl[ls][jj] = lds_read128<jj * 32 * ROWB>(bL[ls] ^ stage_xor);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    });
   };
 
   // prologue: slices 0 and 1 in flight, slice 0 landed, its first k-half in F0
@@ -385,9 +444,13 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   unsigned sx = 0u;                       // XOR of the stage holding slice kt
   for (int kt = 0; kt < p.ktiles; ++kt) {
     // ---- k-half 0 of slice kt on the matrix pipe, k-half 1 on its way to registers
+#ifdef FCP_BIG_V2
     read_frags(SET1, sx);
     __builtin_amdgcn_sched_barrier(0);
     mfmas(SET0);
+#else
+    mfmas_reads(SET0, SET1, sx);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     BPROBE(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -395,25 +458,28 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     __builtin_amdgcn_s_barrier();                          // slice kt+1 visible; nobody reads slice kt's stage again
     __builtin_amdgcn_sched_barrier(0);
     BPROBE(1);
+#ifdef FCP_BIG_V2
     if (kt + 1 < p.ktiles) read_frags(SET0, sx ^ (unsigned)STAGE);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- k-half 1 of slice kt, and the DMA of slice kt+2 into the stage that has just died.  An LDS-DMA instruction
-    //      holds its wave until the vector-memory path has taken the 64 requests: with all eight waves issuing their
-    //      A_LD + B_LD instructions at once (64 KiB per slice through a 64 B/clk path) cycle probes showed BOTH waves of
-    //      a SIMD stuck there for 800-1700 cycles per slice with the matrix pipe idle.  The two waves of a SIMD (w, w+4)
-    //      therefore take the two jobs in opposite order: one feeds the matrix pipe while the other sits in the queue.
-#ifdef FCP_BIG_V1
-    const bool dma_first = true;
-#else
-    const bool dma_first = wave_u >= 4;
 #endif
+    // ---- k-half 1 of slice kt (k-half 0 of slice kt+1 on its way to registers), and the DMA of slice kt+2 into the
+    //      stage that has just died.  An LDS-DMA instruction holds its wave until the vector-memory path has taken the
+    //      64 requests: with all eight waves issuing their A_LD + B_LD instructions at once (64 KiB per slice through a
+    //      64 B/clk path) cycle probes showed BOTH waves of a SIMD stuck there for 800-1700 cycles per slice with the
+    //      matrix pipe idle.  The two waves of a SIMD (w, w+4) therefore take the two jobs in opposite order: one
+    //      feeds the matrix pipe while the other sits in the queue.
+    const bool dma_first = wave_u >= 4;
     if (dma_first && kt + 2 < p.ktiles) {
       advance();
       dma_slice(kt + 2, kt & 1);
     }
     __builtin_amdgcn_sched_barrier(0);
     BPROBE(2);
+#ifdef FCP_BIG_V2
     mfmas(SET1);
+#else
+    mfmas_reads(SET1, SET0, sx ^ (unsigned)STAGE);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (!dma_first && kt + 2 < p.ktiles) {
       advance();
