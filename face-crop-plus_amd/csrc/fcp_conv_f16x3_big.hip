@@ -10,9 +10,11 @@
 //    SIMD against one DMA of 64 (48) KiB: half (three quarters of) the operand bytes per FLOP of the
 //    128x128 kernel, and a whole iteration for the DMA to land.
 //  * two LDS stages, ONE barrier per slice.  Per iteration kt:
-//        issue reads F1 <- (slice kt, k-half 1)        | MFMAs on F0 (slice kt, k-half 0)
+//        MFMAs on F0 (slice kt, k-half 0) with the reads F1 <- (slice kt, k-half 1) between them
 //        wait lgkmcnt(0), vmcnt(0); s_barrier           -- slice kt+1 visible, slice kt's stage dead
-//        issue reads F0 <- (slice kt+1, k-half 0); DMA slice kt+2 -> dead stage | MFMAs on F1
+//        MFMAs on F1 with the reads F0 <- (slice kt+1, k-half 0) between them; DMA slice kt+2 -> dead stage,
+//        issued BEFORE these MFMAs by waves 4..7 and AFTER them by waves 0..3 (the two waves of a SIMD never sit
+//        in the vector-memory queue at the same time)
 //    The fragment reads are inline-asm ds_read_b128: the compiler's waitcnt pass would otherwise
 //    drain the pending LDS-DMA (vmcnt(0)) in front of every LDS read.
 #include "fcp_conv_common.h"
@@ -352,32 +354,6 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   };
   constexpr std::integral_constant<int, 0> SET0{};
   constexpr std::integral_constant<int, 1> SET1{};
-  auto mfmas = [&](auto set_c) {
-    constexpr int set = decltype(set_c)::value;
-#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 2)      // no MFMAs (fragments and accumulators stay live)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]) : "v"(fal[set][i]), "v"(fah[set][i]), "v"(fbh[set][j]), "v"(fbl[set][j]));
-    return;
-#endif
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[set][i], fbh[set][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][i], fbl[set][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][i], fbh[set][j], acc[i][j], 0, 0, 0);
-  };
-
   // MFMAs on fragment set CS with the reads of set LS (from the stage at `stage_xor`) between them, one read per
   // TM * TN * 3 / (2 TM + 2 TN) MFMAs: the LDS requests of the eight lockstep waves arrive spread over the phase
   // instead of as one burst of 8 x (2 TM + 2 TN) in front of it.  (Reads past the last slice fetch stale LDS
@@ -444,13 +420,7 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   unsigned sx = 0u;                       // XOR of the stage holding slice kt
   for (int kt = 0; kt < p.ktiles; ++kt) {
     // ---- k-half 0 of slice kt on the matrix pipe, k-half 1 on its way to registers
-#ifdef FCP_BIG_V2
-    read_frags(SET1, sx);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(SET0);
-#else
     mfmas_reads(SET0, SET1, sx);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     BPROBE(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -458,10 +428,6 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     __builtin_amdgcn_s_barrier();                          // slice kt+1 visible; nobody reads slice kt's stage again
     __builtin_amdgcn_sched_barrier(0);
     BPROBE(1);
-#ifdef FCP_BIG_V2
-    if (kt + 1 < p.ktiles) read_frags(SET0, sx ^ (unsigned)STAGE);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     // ---- k-half 1 of slice kt (k-half 0 of slice kt+1 on its way to registers), and the DMA of slice kt+2 into the
     //      stage that has just died.  An LDS-DMA instruction holds its wave until the vector-memory path has taken the
     //      64 requests: with all eight waves issuing their A_LD + B_LD instructions at once (64 KiB per slice through a
@@ -475,11 +441,7 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     BPROBE(2);
-#ifdef FCP_BIG_V2
-    mfmas(SET1);
-#else
     mfmas_reads(SET1, SET0, sx ^ (unsigned)STAGE);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if (!dma_first && kt + 2 < p.ktiles) {
       advance();
