@@ -99,7 +99,8 @@ typedef struct fcp_conv_desc {
   int32_t tile_m;     /* 0 / 128: 128-row workgroup tiles; 256: the 256-row, 8-wave kernel (precision 1,
                          split32 input, no cin4 / in_up2; tile_n 128 or 256); 1: the halo-tile kernel
                          for 3x3 / stride 1 / pad 1 convs with cout <= 64 (8 x 32 pixel patches, precision 1,
-                         split32 input; tile_n ignored) */
+                         split32 input, cin >= 64, cout % 8 == 0, wscale / bias 16-byte aligned, |out view| < 4 GiB;
+                         tile_n ignored) */
   /* Two-source 1x1 conv (K concatenation): the trailing cin2 of the cin input channels come from
    * in2, a split32 tensor (n, in2_h, in2_w, in2_ld) sampled at (ho*in2_stride, wo*in2_stride); the
    * leading cin - cin2 channels come from `in` as usual.  This is how a ResNet bottleneck's
