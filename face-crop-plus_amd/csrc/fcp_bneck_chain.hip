@@ -348,8 +348,16 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
   if (nch > 0) load_res(0);
   __builtin_amdgcn_sched_barrier(0);
 
+  f16x8 ah[CS][2], al[CS][2];                                    // phase-2 A fragments (T2), loaded in chunk 0
+#ifdef FCP_CHAIN_PROBE   // cycle attribution of the chunk loop (experiment builds): workgroup 0, lane 0 of each wave
+  unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+#define CPROBE(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); pc[k] += t_ - pt; pt = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CPROBE(k) do { } while (0)
+#endif
   for (int j = 0; j < nch; ++j) {
     const bool more = j + 1 < NCH;
+    CPROBE(5);
     // ---- top: this chunk's filters have landed (everything younger may fly), every wave is done with chunk j - 1
     // (W1DB false: group j was issued at top(j-1) and already forced by the wait in front of phase 3 of chunk j-1; the
     //  ops younger than that wait — c(j), R(j), S(j-1) — may all stay in flight, which is the same count)
@@ -358,6 +366,7 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    CPROBE(0);
     if (more) dma_w3(j + 1, (j + 1) & 1);
     if constexpr (W1DB) {
       if (more) dma_w1(j + 1, (j + 1) & 1);
@@ -366,18 +375,41 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    // ---- phase 2 operands: T2 (A) and filter group j (B), all K slices
-    f16x8 ah[CS][2], al[CS][2], bh[CS][2], bl[CS][2];            // [slice][k-half]
+    CPROBE(1);
+    // ---- phase 2 operands: T2 (A: the wave's own 32 rows, the same for every chunk — read once, kept in registers) and
+    //      filter group j (B), all K slices
+    f16x8 bh[CS][2], bl[CS][2];                                  // [slice][k-half]
     const char* b2base = lds + W3B_OFF + (j & 1) * W3CH + l31 * ROWB;
+    if (j == 0) {
+#pragma unroll
+      for (int sl = 0; sl < CS; ++sl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          ah[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offH[s]);
+          al[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offL[s]);
+        }
+    }
 #pragma unroll
     for (int sl = 0; sl < CS; ++sl)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        ah[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offH[s]);
-        al[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offL[s]);
         bh[sl][s] = *reinterpret_cast<const f16x8*>(b2base + sl * 4096 + offH[s]);
         bl[sl][s] = *reinterpret_cast<const f16x8*>(b2base + sl * 4096 + offL[s]);
       }
+    // conv1' fragments of this chunk (W1DB: slice j landed with filter group j): requested behind the phase-2 operands,
+    // they arrive under the phase-2 MFMAs and phase 3 starts with only its two T3 fragments per k-half to wait for
+    f16x8 dh[2][TN3], dl[2][TN3];                                // [k-half][column tile]
+    if constexpr (W1DB) {
+      const char* w1b = lds + W1B_OFF + (j & 1) * (CN * ROWB);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < TN3; ++t) {
+          dh[s][t] = *reinterpret_cast<const f16x8*>(w1b + (t * 32 + l31) * ROWB + offH[s]);
+          dl[s][t] = *reinterpret_cast<const f16x8*>(w1b + (t * 32 + l31) * ROWB + offL[s]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     f32x16 acc2;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
@@ -389,6 +421,7 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[sl][s], acc2, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[sl][s], acc2, 0, 0, 0);
       }
+    CPROBE(2);
     // ---- acc2 * ws3 + b3 (per lane: one channel) -> the wave's rows of the fp32 tile.  Channel group q of a row is
     //      stored in the two 16-byte pieces the split32 image of that group will occupy (hi piece q ^ sw, lo piece
     //      (4 + q) ^ sw), so the epilogue rewrites each item in place.
@@ -429,6 +462,7 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
       *reinterpret_cast<u32x4_t*>(crow + (((4 + eq) ^ sw) << 4)) = olo[it];
     }
     __builtin_amdgcn_sched_barrier(0);
+    CPROBE(3);
     asm volatile("" ::: "memory");
     if (more) {                                                  // a chunk ahead: the lane's channel constants, the residual
       ws_l = p.ws3[(j + 1) * 32 + l31];
@@ -437,6 +471,7 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    CPROBE(4);
     if constexpr (!W1DB) {                                       // single conv1' buffer: slice j was issued at the top
       if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NRES) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -449,13 +484,15 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     const char* w1base = lds + W1B_OFF + (W1DB ? (j & 1) * (CN * ROWB) : 0);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      f16x8 ch, cl, dh[TN3], dl[TN3];
+      f16x8 ch, cl;
       ch = *reinterpret_cast<const f16x8*>(a3base + offH[s]);
       cl = *reinterpret_cast<const f16x8*>(a3base + offL[s]);
+      if constexpr (!W1DB) {
 #pragma unroll
-      for (int t = 0; t < TN3; ++t) {
-        dh[t] = *reinterpret_cast<const f16x8*>(w1base + (t * 32 + l31) * ROWB + offH[s]);
-        dl[t] = *reinterpret_cast<const f16x8*>(w1base + (t * 32 + l31) * ROWB + offL[s]);
+        for (int t = 0; t < TN3; ++t) {
+          dh[s][t] = *reinterpret_cast<const f16x8*>(w1base + (t * 32 + l31) * ROWB + offH[s]);
+          dl[s][t] = *reinterpret_cast<const f16x8*>(w1base + (t * 32 + l31) * ROWB + offL[s]);
+        }
       }
       if (s == 0) {
         __builtin_amdgcn_sched_barrier(0);
@@ -471,13 +508,19 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
       }
 #pragma unroll
       for (int t = 0; t < TN3; ++t) {
-        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, dh[t], acc3[t], 0, 0, 0);
-        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dl[t], acc3[t], 0, 0, 0);
-        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dh[t], acc3[t], 0, 0, 0);
+        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, dh[s][t], acc3[t], 0, 0, 0);
+        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dl[s][t], acc3[t], 0, 0, 0);
+        acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dh[s][t], acc3[t], 0, 0, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+#ifdef FCP_CHAIN_PROBE
+  CPROBE(5);
+  if (blockIdx.x == 0 && lane == 0)
+    printf("wave %d: %d chunks; wait+barrier %llu, filter DMA issue %llu, phase 2 %llu, epilogue %llu, scale/residual loads %llu, phase 3 + stores %llu\n",
+           wave, nch, pc[0], pc[1], pc[2], pc[3], pc[4], pc[5]);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
