@@ -65,7 +65,12 @@ constexpr bool w1_double(int cn, bool has_c2) { return !(has_c2 && cn == 128); }
 constexpr int w3b_off(int cn, bool has_c2) { return W1B_OFF + (w1_double(cn, has_c2) ? 2 : 1) * cn * 128; }   // conv3 filter groups, 2 x (CW * 128 B)
 // region 0 = phase-1 stages | epilogue tiles | chunk buffers; the operand tile T2 (BM x CW, 4 B per element) follows it
 constexpr int r0_bytes(int cw, int cn, bool has_c2) { return has_c2 ? 2 * STAGE : w3b_off(cn, has_c2) + 2 * cw * 128; }
-constexpr int lds_bytes(int cw, int cn, bool has_c2) { return r0_bytes(cw, cn, has_c2) + BM * cw * 4; }   // 80 KiB (two per CU) | 128-144 KiB
+// Where region 0 + T2 would not fit (256-wide pair: 144 + 128 KiB), T2 ALIASES the chunk buffers: a wave's T2 fragments are
+// the same for every chunk and live in registers, so the tile is only needed until they have been read.
+constexpr bool alias_t2(int cw, int cn, bool has_c2) { return !has_c2 && r0_bytes(cw, cn, has_c2) + BM * cw * 4 > 160 * 1024; }
+constexpr int lds_bytes(int cw, int cn, bool has_c2) {   // 80 KiB (two per CU) | 128-144 KiB
+  return alias_t2(cw, cn, has_c2) ? r0_bytes(cw, cn, has_c2) : r0_bytes(cw, cn, has_c2) + BM * cw * 4;
+}
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 
@@ -76,8 +81,12 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
   constexpr int CS = CW / 32;                       // K slices of conv3
   constexpr int NCH = NOUT / 32;                    // groups of 32 conv3 filters
   constexpr int W3CH = CW * 128;                    // bytes of one conv3 filter group in LDS
-  constexpr int T2_OFF = r0_bytes(CW, CN, HAS_C2);
+  constexpr bool ALIAS = alias_t2(CW, CN, HAS_C2);
+  constexpr int T2_OFF = ALIAS ? W1B_OFF : r0_bytes(CW, CN, HAS_C2);
+  static_assert(!ALIAS || W1B_OFF + BM * CW * 4 <= r0_bytes(CW, CN, HAS_C2), "aliased T2 must fit the chunk buffers");
+  static_assert(lds_bytes(CW, CN, HAS_C2) <= 160 * 1024, "LDS budget");
   constexpr bool W1DB = w1_double(CN, HAS_C2);
+  constexpr bool W1PRE = W1DB && CN <= 128;         // conv1' fragments of a chunk requested under phase 2 (registers permitting)
   constexpr int W3B_OFF = w3b_off(CN, HAS_C2);
   static_assert(!HAS_C2 || W3B_OFF + 2 * W3CH <= 2 * STAGE, "chunk buffers must fit the phase-1 stage region");
   constexpr int NRES = HAS_RES ? 4 : 0;             // residual loads per chunk and thread
@@ -341,6 +350,25 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
   };
   const int nch = FCP_ABLATE(p, 8) ? 0 : NCH;
   float ws_l = p.ws3[l31], b_l = p.b3[l31];                      // this lane's conv3 channel of chunk 0 (MFMA layout: col = lane & 31)
+  f16x8 ah[CS][2], al[CS][2];                                    // phase-2 A fragments: the wave's own 32 rows of T2, [slice][k-half]
+  auto read_a2 = [&]() {
+#pragma unroll
+    for (int sl = 0; sl < CS; ++sl)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        ah[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offH[s]);
+        al[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offL[s]);
+      }
+  };
+  if constexpr (ALIAS) {                                         // T2 shares LDS with the chunk buffers: fragments first, filters after
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_a2();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
   asm volatile("" ::: "memory");
   dma_w3(0, 0);
   if constexpr (W1DB) dma_w1(0, 0);
@@ -348,7 +376,6 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
   if (nch > 0) load_res(0);
   __builtin_amdgcn_sched_barrier(0);
 
-  f16x8 ah[CS][2], al[CS][2];                                    // phase-2 A fragments (T2), loaded in chunk 0
 #ifdef FCP_CHAIN_PROBE   // cycle attribution of the chunk loop (experiment builds): workgroup 0, lane 0 of each wave
   unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
 #define CPROBE(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); pc[k] += t_ - pt; pt = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -378,28 +405,26 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     CPROBE(1);
     // ---- phase 2 operands: T2 (A: the wave's own 32 rows, the same for every chunk — read once, kept in registers) and
     //      filter group j (B), all K slices
-    f16x8 bh[CS][2], bl[CS][2];                                  // [slice][k-half]
     const char* b2base = lds + W3B_OFF + (j & 1) * W3CH + l31 * ROWB;
-    if (j == 0) {
+    if constexpr (!ALIAS) {
+      if (j == 0) read_a2();
+    }
+    constexpr int BG = CS <= 4 ? CS : 2;                         // slices of filter fragments in flight (all of them up to CS = 4)
+    f16x8 bh[2][BG][2], bl[2][BG][2];                            // [buffer][slice in group][k-half]
+    auto read_b2 = [&](int buf, int g) {
 #pragma unroll
-      for (int sl = 0; sl < CS; ++sl)
+      for (int q = 0; q < BG; ++q)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          ah[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offH[s]);
-          al[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offL[s]);
+          bh[buf][q][s] = *reinterpret_cast<const f16x8*>(b2base + (g * BG + q) * 4096 + offH[s]);
+          bl[buf][q][s] = *reinterpret_cast<const f16x8*>(b2base + (g * BG + q) * 4096 + offL[s]);
         }
-    }
-#pragma unroll
-    for (int sl = 0; sl < CS; ++sl)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bh[sl][s] = *reinterpret_cast<const f16x8*>(b2base + sl * 4096 + offH[s]);
-        bl[sl][s] = *reinterpret_cast<const f16x8*>(b2base + sl * 4096 + offL[s]);
-      }
+    };
+    read_b2(0, 0);
     // conv1' fragments of this chunk (W1DB: slice j landed with filter group j): requested behind the phase-2 operands,
     // they arrive under the phase-2 MFMAs and phase 3 starts with only its two T3 fragments per k-half to wait for
     f16x8 dh[2][TN3], dl[2][TN3];                                // [k-half][column tile]
-    if constexpr (W1DB) {
+    if constexpr (W1PRE) {
       const char* w1b = lds + W1B_OFF + (j & 1) * (CN * ROWB);
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -414,13 +439,18 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < CS; ++sl)
+    for (int g = 0; g < CS / BG; ++g) {
+      if (g + 1 < CS / BG) read_b2((g + 1) & 1, g + 1);            // next group's fragments under this group's MFMAs
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl][s], bh[sl][s], acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[sl][s], acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[sl][s], acc2, 0, 0, 0);
-      }
+      for (int q = 0; q < BG; ++q)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int sl = g * BG + q;
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[g & 1][q][s], acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
+        }
+    }
     CPROBE(2);
     // ---- acc2 * ws3 + b3 (per lane: one channel) -> the wave's rows of the fp32 tile.  Channel group q of a row is
     //      stored in the two 16-byte pieces the split32 image of that group will occupy (hi piece q ^ sw, lo piece
@@ -487,7 +517,7 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
       f16x8 ch, cl;
       ch = *reinterpret_cast<const f16x8*>(a3base + offH[s]);
       cl = *reinterpret_cast<const f16x8*>(a3base + offL[s]);
-      if constexpr (!W1DB) {
+      if constexpr (!W1PRE) {
 #pragma unroll
         for (int t = 0; t < TN3; ++t) {
           dh[s][t] = *reinterpret_cast<const f16x8*>(w1base + (t * 32 + l31) * ROWB + offH[s]);
@@ -592,10 +622,11 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   const bool has_c2 = d->w2 != nullptr;
   FCP_REQUIRE(!has_c2 || (d->ws2 && d->b2), "chain: conv2 needs its scales and bias");
   // supported shapes: (c 64, conv2, nout 256, residual, cn 64 | 128)   (c 128, no conv2, nout 512, residual, cn 128)
-  //                   (c 128, no conv2, nout 256, no residual, cn 64)
+  //                   (c 128, no conv2, nout 256, no residual, cn 64)   (c 256, no conv2, nout 1024, residual, cn 256)
   const int variant = (has_c2 && d->c == 64 && d->nout == 256 && d->res && (d->cn == 64 || d->cn == 128)) ? (d->cn == 64 ? 1 : 2)
                     : (!has_c2 && d->c == 128 && d->nout == 512 && d->res && d->cn == 128) ? 3
-                    : (!has_c2 && d->c == 128 && d->nout == 256 && !d->res && d->cn == 64) ? 4 : 0;
+                    : (!has_c2 && d->c == 128 && d->nout == 256 && !d->res && d->cn == 64) ? 4
+                    : (!has_c2 && d->c == 256 && d->nout == 1024 && d->res && d->cn == 256) ? 5 : 0;
   FCP_REQUIRE(variant != 0, "chain: unsupported shape (c %d, conv2 %d, nout %d, residual %d, cn %d)", d->c, (int)has_c2, d->nout,
               d->res != nullptr, d->cn);
   FCP_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "chain: bad sizes");
@@ -615,7 +646,7 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   const unsigned long out_bytes = (unsigned long)M * d->out_ld * 4ul;
   FCP_REQUIRE(out_bytes < 0xFFFFFFF0ul, "chain: out must span less than 4 GiB");
   k.out_bytes = (unsigned)out_bytes;
-  k.w1n = reinterpret_cast<const float*>(d->w1n); k.w1n_bytes = (unsigned)(128 * d->nout * 4); k.ws1n = d->ws1n; k.b1n = d->b1n;
+  k.w1n = reinterpret_cast<const float*>(d->w1n); k.w1n_bytes = (unsigned)(fcp_cdiv(d->cn, 128) * 128 * d->nout * 4); k.ws1n = d->ws1n; k.b1n = d->b1n;
   k.t1n = d->t1n; k.t1n_ld = d->t1n_ld;
   k.n = d->n; k.h = d->h; k.w = d->w; k.M = (int)M;
   static const int nt_env = getenv("FCP_NT_STORE") ? atoi(getenv("FCP_NT_STORE")) : 1;
@@ -631,6 +662,7 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
     case 1: return launch<64, 64, 256, true, true>(k, s);
     case 2: return launch<128, 64, 256, true, true>(k, s);
     case 3: return launch<128, 128, 512, false, true>(k, s);
+    case 5: return launch<256, 256, 1024, false, true>(k, s);
     default: return launch<64, 128, 256, false, false>(k, s);
   }
 }

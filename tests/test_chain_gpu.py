@@ -90,19 +90,20 @@ def test_detector_same_bits_with_and_without_chain(device):
     assert torch.equal(a["landmarks"], b["landmarks"]) and torch.equal(a["face_offset"], b["face_offset"])
 
 
-@pytest.mark.parametrize("n,h,w,residual", [(2, 37, 45, True), (1, 16, 16, True), (3, 80, 80, True), (2, 33, 29, False),
-                                            (1, 160, 160, False)])
-def test_pair_equals_two_convs(n, h, w, residual, device):
+@pytest.mark.parametrize("n,h,w,residual,c", [(2, 37, 45, True, 128), (1, 16, 16, True, 128), (3, 80, 80, True, 128), (2, 33, 29, False, 128),
+                                              (1, 160, 160, False, 128), (2, 21, 19, True, 256), (1, 8, 16, True, 256), (5, 40, 40, True, 256)])
+def test_pair_equals_two_convs(n, h, w, residual, c, device):
     """The pair forms (no conv2): conv3 (+ identity) + next conv1 on 128-channel inputs — layer-2 identity blocks
     (128 -> 512 -> 128, residual) and layer1.0's K-concatenated conv3 + downsample with layer1.1.conv1
-    (128 -> 256 -> 64, no residual).  Bit-identical to the two stand-alone convolutions."""
+    (128 -> 256 -> 64, no residual); layer-3 identity blocks on 256-channel inputs (256 -> 1024 -> 256, residual; the
+    operand tile aliases the chunk buffers there).  Bit-identical to the two stand-alone convolutions."""
     from face_crop_plus_amd import engine as E
     g = torch.Generator().manual_seed(n * 100 + h + int(residual))
-    nout, cn = (512, 128) if residual else (256, 64)
-    w3 = torch.randn(nout, 128, 1, 1, generator=g) * (2 / 128) ** 0.5
+    nout, cn = ((512, 128) if residual else (256, 64)) if c == 128 else (1024, 256)
+    w3 = torch.randn(nout, c, 1, 1, generator=g) * (2 / c) ** 0.5
     w1 = torch.randn(cn, nout, 1, 1, generator=g) * (2 / nout) ** 0.5
     bn3, bn1 = _bn(nout, g), _bn(cn, g)
-    t = F.relu(torch.randn(n, 128, h, w, generator=g))
+    t = F.relu(torch.randn(n, c, h, w, generator=g))
     x = F.relu(torch.randn(n, nout, h, w, generator=g)) if residual else None
     with E.default_precision("f16x3"):
         pc3 = E.pack_conv(w3, None, bn3, 1, 0, device)
@@ -126,6 +127,6 @@ def test_pair_equals_two_convs(n, h, w, residual, device):
 def test_chain_rejects_unsupported_shapes(device):
     from face_crop_plus_amd import engine as E
     with E.default_precision("f16x3"):
-        pc3 = E.pack_conv(torch.randn(1024, 256, 1, 1), torch.zeros(1024), None, 1, 0, device)
-        pc1 = E.pack_conv(torch.randn(256, 1024, 1, 1), torch.zeros(256), None, 1, 0, device)
+        pc3 = E.pack_conv(torch.randn(2048, 512, 1, 1), torch.zeros(2048), None, 1, 0, device)
+        pc1 = E.pack_conv(torch.randn(512, 2048, 1, 1), torch.zeros(512), None, 1, 0, device)
     assert not E.chain_supported(None, pc3, pc1)

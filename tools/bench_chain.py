@@ -55,3 +55,16 @@ for (hh, nout, cn, residual) in ((80, 512, 128, True), (160, 256, 64, False)):
     fl = (pc3.flops_per_pixel + pc1.flops_per_pixel) * m
     print(f"pair {hh}x{hh} 128->{nout}->{cn} res={residual}: {tc:7.1f} us ({gb / tc * 1e6:5.0f} GB/s algorithmic, {fl / tc / 1e6:5.0f} TFLOP/s) | "
           f"separate {t3:6.1f} + {t1_:6.1f} = {t3 + t1_:7.1f} us  ablate={os.environ.get('FCP_CHAIN_ABLATE', '0')}", flush=True)
+
+# ---- layer-3 pair (256 -> 1024 -> 256 at 40x40)
+if True:
+    hh, nout, cn = 40, 1024, 256
+    pc3 = mk(nout, 256, 1)
+    pc1 = mk(cn, nout, 1)
+    t = E.f32_to_split32(E.Act(torch.randn(b, hh, hh, 256, device=dev).relu()))
+    xr = E.f32_to_split32(E.Act(torch.randn(b, hh, hh, nout, device=dev).relu()))
+    out, t1n = E.Act.empty(b, hh, hh, nout, dev, 1), E.Act.empty(b, hh, hh, cn, dev, 1)
+    t3 = timeit(lambda: E.conv(pc3, t, out, act_slope=0.0, res1=xr))
+    t1_ = timeit(lambda: E.conv(pc1, out, t1n, act_slope=0.0))
+    tc = timeit(lambda: E.bottleneck_chain(None, pc3, pc1, t, xr, out, t1n)) if E.chain_supported(None, pc3, pc1) else float("nan")
+    print(f"pair {hh}x{hh} 256->{nout}->{cn} res=True: {tc:7.1f} us | separate {t3:6.1f} + {t1_:6.1f} = {t3 + t1_:7.1f} us", flush=True)
