@@ -35,6 +35,8 @@
 // 128 KiB of LDS, one workgroup per CU.
 #include "fcp_conv_common.h"
 
+#include <type_traits>
+
 using namespace fcp_conv;
 
 namespace {
@@ -74,6 +76,14 @@ constexpr int lds_bytes(int cw, int cn, bool has_c2) {   // 80 KiB (two per CU) 
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES>
 __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const ChainK p) {
   static_assert(!HAS_C2 || CW == C, "phase 1 is written for 64-channel bottlenecks");
@@ -86,6 +96,14 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
   static_assert(!ALIAS || W1B_OFF + BM * CW * 4 <= r0_bytes(CW, CN, HAS_C2), "aliased T2 must fit the chunk buffers");
   static_assert(lds_bytes(CW, CN, HAS_C2) <= 160 * 1024, "LDS budget");
   constexpr bool W1DB = w1_double(CN, HAS_C2);
+  // The next chunk's filter DMAs are issued one at a time BETWEEN the phase-2 MFMAs where both buffers are double
+  // (an LDS-DMA instruction holds the wave until the vector-memory path has taken it: as a burst of CS + CN / 32 at the top
+  // of the chunk that was ~1000-2000 cycles with the matrix pipe idle; behind an MFMA it costs the difference)
+#ifdef FCP_CHAIN_BURST
+  constexpr bool SPREAD = false;
+#else
+  constexpr bool SPREAD = W1DB && (CS + CN / 32 <= 2 * CS);
+#endif
   constexpr bool W1PRE = W1DB && CN <= 128;         // conv1' fragments of a chunk requested under phase 2 (registers permitting)
   constexpr int W3B_OFF = w3b_off(CN, HAS_C2);
   static_assert(!HAS_C2 || W3B_OFF + 2 * W3CH <= 2 * STAGE, "chunk buffers must fit the phase-1 stage region");
@@ -301,6 +319,23 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + 8 * i * ROWB), 16, (int)src, 0, 0, 0);
     }
   };
+  // instruction k of {filter group j, conv1' slice j} (CS + CN / 32 per wave), for issue between the phase-2 MFMAs
+  constexpr int NDMA = CS + CN / 32;
+  auto dma_one = [&](auto kc, int j, int buf) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k < CS) {
+      const int g = wave_u * CS + k, sl = g >> 2, r = (g & 3) * 8 + (lane >> 3);
+      char* dst = lds + W3B_OFF + buf * W3CH + sl * 4096 + (g & 3) * 8 * ROWB;
+      const unsigned src = (unsigned)((j * 32 + r) * (CW * 4) + sl * 128 + (((lane & 7) ^ swz(r)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (__attribute__((address_space(3))) void*)dst, 16, (int)src, 0, 0, 0);
+    } else {
+      constexpr int i = k - CS;
+      char* dst = lds + W1B_OFF + buf * (CN * ROWB) + wave_u * (CN / 4) * ROWB;
+      const int r = wave_u * (CN / 4) + 8 * i + (lane >> 3);
+      const unsigned src = (unsigned)(r * (NOUT * 4) + j * 128 + (((lane & 7) ^ swz(r)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + 8 * i * ROWB), 16, (int)src, 0, 0, 0);
+    }
+  };
 
   f32x16 acc3[TN3];
 #pragma unroll
@@ -394,11 +429,13 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     CPROBE(0);
-    if (more) dma_w3(j + 1, (j + 1) & 1);
-    if constexpr (W1DB) {
-      if (more) dma_w1(j + 1, (j + 1) & 1);
-    } else {
-      dma_w1(j, 0);
+    if constexpr (!SPREAD) {
+      if (more) dma_w3(j + 1, (j + 1) & 1);
+      if constexpr (W1DB) {
+        if (more) dma_w1(j + 1, (j + 1) & 1);
+      } else {
+        dma_w1(j, 0);
+      }
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -438,19 +475,21 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     f32x16 acc2;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
-#pragma unroll
-    for (int g = 0; g < CS / BG; ++g) {
-      if (g + 1 < CS / BG) read_b2((g + 1) & 1, g + 1);            // next group's fragments under this group's MFMAs
-#pragma unroll
-      for (int q = 0; q < BG; ++q)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int sl = g * BG + q;
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[g & 1][q][s], acc2, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
+    static_for<0, CS / BG>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + 1 < CS / BG) read_b2((g + 1) & 1, g + 1);  // next group's fragments under this group's MFMAs
+      static_for<0, 2 * BG>([&](auto tc) {
+        constexpr int q = decltype(tc)::value / 2, s = decltype(tc)::value % 2, sl = g * BG + q, trip = 2 * sl + s;
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[g & 1][q][s], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
+        if constexpr (SPREAD && trip < NDMA) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) dma_one(std::integral_constant<int, trip>{}, j + 1, (j + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
-    }
+      });
+    });
     CPROBE(2);
     // ---- acc2 * ws3 + b3 (per lane: one channel) -> the wave's rows of the fp32 tile.  Channel group q of a row is
     //      stored in the two 16-byte pieces the split32 image of that group will occupy (hi piece q ^ sw, lo piece
