@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
 #ifdef FCP_CHAIN_BURST
   constexpr bool SPREAD = false;
 #else
-  constexpr bool SPREAD = W1DB && (CS + CN / 32 <= 2 * CS);
+  constexpr bool SPREAD = W1DB;
 #endif
   constexpr bool W1PRE = W1DB && CN <= 128;         // conv1' fragments of a chunk requested under phase 2 (registers permitting)
   constexpr int W3B_OFF = w3b_off(CN, HAS_C2);
@@ -483,11 +483,16 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[g & 1][q][s], acc2, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
-        if constexpr (SPREAD && trip < NDMA) {
+        constexpr int PER = (NDMA + 2 * CS - 1) / (2 * CS);       // DMA instructions per MFMA triple (1, or 2 where CN > 32 CS)
+        if constexpr (SPREAD && trip * PER < NDMA) {
           __builtin_amdgcn_sched_barrier(0);
-          if (more) dma_one(std::integral_constant<int, trip>{}, j + 1, (j + 1) & 1);
+          if (more) {
+            dma_one(std::integral_constant<int, trip * PER>{}, j + 1, (j + 1) & 1);
+            if constexpr (PER == 2 && trip * PER + 1 < NDMA) dma_one(std::integral_constant<int, trip * PER + 1>{}, j + 1, (j + 1) & 1);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
+        static_assert(PER <= 2, "at most two DMA instructions per MFMA triple");
       });
     });
     CPROBE(2);
@@ -662,10 +667,12 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   FCP_REQUIRE(!has_c2 || (d->ws2 && d->b2), "chain: conv2 needs its scales and bias");
   // supported shapes: (c 64, conv2, nout 256, residual, cn 64 | 128)   (c 128, no conv2, nout 512, residual, cn 128)
   //                   (c 128, no conv2, nout 256, no residual, cn 64)   (c 256, no conv2, nout 1024, residual, cn 256)
+  //                   (c 128, no conv2, nout 512, residual, cn 256)
   const int variant = (has_c2 && d->c == 64 && d->nout == 256 && d->res && (d->cn == 64 || d->cn == 128)) ? (d->cn == 64 ? 1 : 2)
                     : (!has_c2 && d->c == 128 && d->nout == 512 && d->res && d->cn == 128) ? 3
                     : (!has_c2 && d->c == 128 && d->nout == 256 && !d->res && d->cn == 64) ? 4
-                    : (!has_c2 && d->c == 256 && d->nout == 1024 && d->res && d->cn == 256) ? 5 : 0;
+                    : (!has_c2 && d->c == 256 && d->nout == 1024 && d->res && d->cn == 256) ? 5
+                    : (!has_c2 && d->c == 128 && d->nout == 512 && d->res && d->cn == 256) ? 6 : 0;
   FCP_REQUIRE(variant != 0, "chain: unsupported shape (c %d, conv2 %d, nout %d, residual %d, cn %d)", d->c, (int)has_c2, d->nout,
               d->res != nullptr, d->cn);
   FCP_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "chain: bad sizes");
@@ -702,6 +709,7 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
     case 2: return launch<128, 64, 256, true, true>(k, s);
     case 3: return launch<128, 128, 512, false, true>(k, s);
     case 5: return launch<256, 256, 1024, false, true>(k, s);
+    case 6: return launch<256, 128, 512, false, true>(k, s);
     default: return launch<64, 128, 256, false, false>(k, s);
   }
 }

@@ -357,7 +357,8 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
 def chain_supported(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, residual: bool = True) -> bool:
     """Shapes ``fcp_bottleneck_chain_f16x3`` covers, all packed for the fp16x3 path with folded-BN bias:
     * with conv2: 64-wide bottleneck (3x3 64->64 / 1, 1x1 64->256 + residual), next conv1 1x1 256 -> 64 | 128;
-    * pair (``pc2`` None): 1x1 128->512 + residual, next conv1 512->128  (layer-2 identity blocks),
+    * pair (``pc2`` None): 1x1 128->512 + residual, next conv1 512->128 | 256  (layer-2 identity blocks; the last one
+      with layer3.0.conv1),
       1x1 256->1024 + residual, next conv1 1024->256  (layer-3 identity blocks), or
       1x1 128->256 without residual, next conv1 256->64  (layer1.0's conv3 + downsample K-concat, layer1.1.conv1)."""
     convs = [pc for pc in (pc2, pc3, pc1n) if pc is not None]
@@ -368,7 +369,8 @@ def chain_supported(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, r
         return ((pc2.cin, pc2.cout, pc2.kh, pc2.kw, pc2.stride, pc2.pad) == (64, 64, 3, 3, 1, 1) and residual
                 and one(pc3, 64, 256) and (one(pc1n, 256, 64) or one(pc1n, 256, 128)))
     if residual:
-        return (one(pc3, 128, 512) and one(pc1n, 512, 128)) or (one(pc3, 256, 1024) and one(pc1n, 1024, 256))
+        return ((one(pc3, 128, 512) and (one(pc1n, 512, 128) or one(pc1n, 512, 256)))
+                or (one(pc3, 256, 1024) and one(pc1n, 1024, 256)))
     return one(pc3, 128, 256) and one(pc1n, 256, 64)
 
 

@@ -166,9 +166,10 @@ class RetinaFace:
                     feats.append(x)
                 continue
             o = E.conv(blk["c2"], o, act_slope=0.0, out_fmt=f)
-            if (chain and blk["ds"] is None and not blk["feat"] and nxt is not None
-                    and E.chain_supported(None, blk["c3"], nxt["c1"])):
-                x, pre = E.bottleneck_chain(None, blk["c3"], nxt["c1"], o, x)          # conv3 (+ identity) + next conv1 (layer 2)
+            if (chain and blk["ds"] is None and nxt is not None and E.chain_supported(None, blk["c3"], nxt["c1"])):
+                x, pre = E.bottleneck_chain(None, blk["c3"], nxt["c1"], o, x)          # conv3 (+ identity) + next conv1 (layers 2-3)
+                if blk["feat"]:
+                    feats.append(x)
                 continue
             idt = x if blk["ds"] is None else E.conv(blk["ds"], x, out_fmt=f)
             x = E.conv(blk["c3"], o, act_slope=0.0, res1=idt, res1_pre=True, out_fmt=f)

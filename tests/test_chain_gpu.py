@@ -91,7 +91,7 @@ def test_detector_same_bits_with_and_without_chain(device):
 
 
 @pytest.mark.parametrize("n,h,w,residual,c", [(2, 37, 45, True, 128), (1, 16, 16, True, 128), (3, 80, 80, True, 128), (2, 33, 29, False, 128),
-                                              (1, 160, 160, False, 128), (2, 21, 19, True, 256), (1, 8, 16, True, 256), (5, 40, 40, True, 256)])
+                                              (1, 160, 160, False, 128), (2, 21, 19, True, 256), (1, 8, 16, True, 256), (5, 40, 40, True, 256), (2, 27, 30, True, -128), (1, 80, 80, True, -128)])
 def test_pair_equals_two_convs(n, h, w, residual, c, device):
     """The pair forms (no conv2): conv3 (+ identity) + next conv1 on 128-channel inputs — layer-2 identity blocks
     (128 -> 512 -> 128, residual) and layer1.0's K-concatenated conv3 + downsample with layer1.1.conv1
@@ -99,7 +99,9 @@ def test_pair_equals_two_convs(n, h, w, residual, c, device):
     operand tile aliases the chunk buffers there).  Bit-identical to the two stand-alone convolutions."""
     from face_crop_plus_amd import engine as E
     g = torch.Generator().manual_seed(n * 100 + h + int(residual))
-    nout, cn = ((512, 128) if residual else (256, 64)) if c == 128 else (1024, 256)
+    wide_next = c < 0                                            # -128: layer 2's last block with layer3.0.conv1 (512 -> 256)
+    c = abs(c)
+    nout, cn = ((512, 256 if wide_next else 128) if residual else (256, 64)) if c == 128 else (1024, 256)
     w3 = torch.randn(nout, c, 1, 1, generator=g) * (2 / c) ** 0.5
     w1 = torch.randn(cn, nout, 1, 1, generator=g) * (2 / nout) ** 0.5
     bn3, bn1 = _bn(nout, g), _bn(cn, g)
