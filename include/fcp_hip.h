@@ -131,11 +131,13 @@ int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);
  * has a bias and a per-filter scale.  All tensors are split32 views (n, h, w, *_ld), 128-byte aligned,
  * *_ld % 32 == 0.  Supported: c = 64 (ResNet-50 layer 1), nout = 256, cn = 64 or 128.
  *
- * Pair forms (w2 == NULL: no conv2, t1 is conv3's input itself, c = 128 channels):
- *     out = relu(conv3_1x1(t1) * ws3 + b3 [+ res])    128 -> nout;     t1n = relu(conv1n_1x1(out) * ws1n + b1n)    nout -> cn
- *   nout = 512, res != NULL, cn = 128   conv3 of a layer-2 identity block + conv1 of the next block
- *   nout = 256, res == NULL, cn = 64    layer1.0: conv3 + downsample as one K-concatenated 1x1 conv over
- *                                       [conv2 out | pooled stem] (engine.py packs it so), + layer1.1.conv1
+ * Pair forms (w2 == NULL: no conv2, t1 is conv3's input itself, c = 128 or 256 channels):
+ *     out = relu(conv3_1x1(t1) * ws3 + b3 [+ res])    c -> nout;     t1n = relu(conv1n_1x1(out) * ws1n + b1n)    nout -> cn
+ *   c = 128, nout = 512,  res != NULL, cn = 128   conv3 of a layer-2 identity block + conv1 of the next block
+ *   c = 128, nout = 512,  res != NULL, cn = 256   layer 2's last block + layer3.0.conv1
+ *   c = 256, nout = 1024, res != NULL, cn = 256   conv3 of a layer-3 identity block + conv1 of the next block
+ *   c = 128, nout = 256,  res == NULL, cn = 64    layer1.0: conv3 + downsample as one K-concatenated 1x1 conv over
+ *                                                 [conv2 out | pooled stem] (engine.py packs it so), + layer1.1.conv1
  * ------------------------------------------------------------------------ */
 typedef struct fcp_chain_desc {
   const float* t1;    /* conv2's input: c channels */
