@@ -67,12 +67,20 @@ constexpr bool w1_double(int cn, bool has_c2) { return !(has_c2 && cn == 128); }
 constexpr int w3b_off(int cn, bool has_c2) { return W1B_OFF + (w1_double(cn, has_c2) ? 2 : 1) * cn * 128; }   // conv3 filter groups, 2 x (CW * 128 B)
 // region 0 = phase-1 stages | epilogue tiles | chunk buffers; the operand tile T2 (BM x CW, 4 B per element) follows it
 constexpr int r0_bytes(int cw, int cn, bool has_c2) { return has_c2 ? 2 * STAGE : w3b_off(cn, has_c2) + 2 * cw * 128; }
-// Where region 0 + T2 would not fit (256-wide pair: 144 + 128 KiB), T2 ALIASES the chunk buffers: a wave's T2 fragments are
-// the same for every chunk and live in registers, so the tile is only needed until they have been read.
+// In the pair forms T2 ALIASES the chunk buffers: a wave's T2 fragments are the same for every chunk and live in
+// registers, so the tile is only needed until they have been read.  That is what lets the 256-wide pair fit at all
+// (144 + 128 KiB otherwise) and brings the 128-wide pairs down to 80 KiB: TWO workgroups per CU, the second one's
+// MFMAs under the first one's epilogue (FCP_CHAIN_NOALIAS: the 128-wide pairs as before, 128-144 KiB, one per CU).
+#ifdef FCP_CHAIN_NOALIAS
 constexpr bool alias_t2(int cw, int cn, bool has_c2) { return !has_c2 && r0_bytes(cw, cn, has_c2) + BM * cw * 4 > 160 * 1024; }
-constexpr int lds_bytes(int cw, int cn, bool has_c2) {   // 80 KiB (two per CU) | 128-144 KiB
-  return alias_t2(cw, cn, has_c2) ? r0_bytes(cw, cn, has_c2) : r0_bytes(cw, cn, has_c2) + BM * cw * 4;
+#else
+constexpr bool alias_t2(int cw, int cn, bool has_c2) { return !has_c2; }
+#endif
+constexpr int lds_bytes(int cw, int cn, bool has_c2) {   // 80 KiB (two per CU) | 112-144 KiB
+  const int r0 = r0_bytes(cw, cn, has_c2), t2 = BM * cw * 4;
+  return !alias_t2(cw, cn, has_c2) ? r0 + t2 : (r0 > W1B_OFF + t2 ? r0 : W1B_OFF + t2);
 }
+constexpr int wgs_per_cu(int cw, int cn, bool has_c2) { return lds_bytes(cw, cn, has_c2) <= 80 * 1024 ? 2 : 1; }
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 
@@ -85,7 +93,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES>
-__global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const ChainK p) {
+__global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c64(const ChainK p) {
   static_assert(!HAS_C2 || CW == C, "phase 1 is written for 64-channel bottlenecks");
   constexpr int TN3 = CN / 32;
   constexpr int CS = CW / 32;                       // K slices of conv3
@@ -93,7 +101,7 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
   constexpr int W3CH = CW * 128;                    // bytes of one conv3 filter group in LDS
   constexpr bool ALIAS = alias_t2(CW, CN, HAS_C2);
   constexpr int T2_OFF = ALIAS ? W1B_OFF : r0_bytes(CW, CN, HAS_C2);
-  static_assert(!ALIAS || W1B_OFF + BM * CW * 4 <= r0_bytes(CW, CN, HAS_C2), "aliased T2 must fit the chunk buffers");
+  constexpr int WGS = wgs_per_cu(CW, CN, HAS_C2);   // two per CU: 256 registers per wave
   static_assert(lds_bytes(CW, CN, HAS_C2) <= 160 * 1024, "LDS budget");
   constexpr bool W1DB = w1_double(CN, HAS_C2);
   // The next chunk's filter DMAs are issued one at a time BETWEEN the phase-2 MFMAs where both buffers are double
@@ -104,7 +112,7 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
 #else
   constexpr bool SPREAD = W1DB;
 #endif
-  constexpr bool W1PRE = W1DB && CN <= 128;         // conv1' fragments of a chunk requested under phase 2 (registers permitting)
+  constexpr bool W1PRE = W1DB && CN <= 128 && (HAS_C2 || WGS == 1);   // conv1' fragments of a chunk requested under phase 2 (registers permitting)
   constexpr int W3B_OFF = w3b_off(CN, HAS_C2);
   static_assert(!HAS_C2 || W3B_OFF + 2 * W3CH <= 2 * STAGE, "chunk buffers must fit the phase-1 stage region");
   constexpr int NRES = HAS_RES ? 4 : 0;             // residual loads per chunk and thread
@@ -446,7 +454,7 @@ __global__ void __launch_bounds__(256, (HAS_C2 ? 2 : 1)) bneck_chain_c64(const C
     if constexpr (!ALIAS) {
       if (j == 0) read_a2();
     }
-    constexpr int BG = CS <= 4 ? CS : 2;                         // slices of filter fragments in flight (all of them up to CS = 4)
+    constexpr int BG = (CS <= 4 && (HAS_C2 || WGS == 1)) ? CS : 2;   // slices of filter fragments in flight (all of them up to CS = 4, registers permitting)
     f16x8 bh[2][BG][2], bl[2][BG][2];                            // [buffer][slice in group][k-half]
     auto read_b2 = [&](int buf, int g) {
 #pragma unroll
