@@ -45,3 +45,8 @@ print(f"same, second one started half a step late:        {run(two, ss, True):8.
 three = two + [bench.Pipeline(dev, sd, batch=32, streams=1, **kw)]
 ss.append(torch.cuda.Stream())
 print(f"three pipelines, batch 32 each:                   {run(three, ss):8.1f} faces/s", flush=True)
+del two, three
+full = [bench.Pipeline(dev, sd, batch=64, streams=1, **kw) for _ in range(2)]
+print(f"two pipelines, batch 64 each (whole steps alternate between two streams): {run(full, ss[:2]):8.1f} faces/s", flush=True)
+full3 = full + [bench.Pipeline(dev, sd, batch=64, streams=1, **kw)]
+print(f"three pipelines, batch 64 each:                   {run(full3, ss[:3]):8.1f} faces/s", flush=True)
