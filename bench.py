@@ -124,15 +124,16 @@ class Pipeline:
                 self.enhanced_total += len(which)
                 self.enh.enhance_u8(imgs, which)
         with trace.range("fcp:align"):
+            # the estimate kernel masks the rows beyond face_offset[n] and adds the number of faces it keeps (a live row
+            # with a non-degenerate transform, cropper.py:529-531) to the device-side total: no counting launches
             crops, ok, _ = self.align.crop_align(imgs, res["img_idx"], res["landmarks"], self.tgt,
-                                                 (self.out_size, self.out_size), 0)
+                                                 (self.out_size, self.out_size), 0,
+                                                 face_count=res["face_offset"][-1:],
+                                                 valid_total=self.face_total if count else None)
         if self.par is not None:
             with trace.range("fcp:parse"):
                 self.par.parse(crops)                    # label maps + class histograms stay on the device
-        if count:
-            nf = torch.clamp(res["face_offset"][-1].to(torch.int64), max=res["max_faces"])
-            valid = (torch.arange(res["max_faces"], device=self.dev) < nf) & (ok != 0)
-            self.face_total.add_(valid.sum())
+        self.last = (res, crops, ok)
         return crops
 
     def describe(self):
@@ -207,13 +208,13 @@ class Pipeline4K(Pipeline):
             self.enh.enhance_u8(imgs, which)
         with trace.range("fcp:align"):
             crops, ok, _ = self.align.crop_align(imgs, res["img_idx"], res["landmarks"], self.tgt,
-                                                 (self.out_size, self.out_size), 0, paddings=self.pads)
+                                                 (self.out_size, self.out_size), 0, paddings=self.pads,
+                                                 face_count=res["face_offset"][-1:],
+                                                 valid_total=self.face_total if count else None)
         with trace.range("fcp:parse"):
             if crops.shape[0]:
                 self.par.parse(crops)
-        if count:
-            valid = (torch.arange(res["max_faces"], device=self.dev) < nf) & (ok != 0)
-            self.face_total.add_(valid.sum())
+        self.last = (res, crops, ok)
         return crops
 
     def describe(self):
@@ -251,10 +252,25 @@ def time_pipeline(p: Pipeline, steps, warmup, autotune=True, dist=None, live_eve
     return time.perf_counter() - t0, p.face_total.clone()
 
 
-def conv_roofline(p: Pipeline, nsteps, live):
+def _pmc_traffic(key):
+    """Committed PMC measurement (HBM bytes per conv launch) of workload `key`, newest round first: counters cannot be
+    read from inside the process, so `traffic` is the rocprofv3 --pmc measurement of the same command."""
+    pdir = os.path.join(ROOT, "profiles")
+    prof = sorted(f for f in os.listdir(pdir) if f.endswith(f"_{key}.json")) if os.path.isdir(pdir) else []
+    if not prof:
+        return None, None
+    with open(os.path.join(pdir, prof[-1])) as f:
+        return round(json.load(f)["hbm_bytes_per_launch"]), "profiles/" + prof[-1]
+
+
+def conv_roofline(p: Pipeline, nsteps, live, timed_ms=None, traffic_key=None):
     """Roofline record of the conv engine from per-launch HIP events on the launch stream: the events of the timed
-    steps (`live`, single-stream runs) or of `nsteps` extra single-stream passes right after the timed region."""
+    steps (`live`, single-stream runs) or of `nsteps` extra single-stream passes right after the timed region.
+    `timed_ms`: ms per step of the timed region (the product configuration, possibly two detector streams): the record
+    then also carries `frac_timed` = algorithmic conv FLOP / whole-step time / peak — a lower bound of what the conv
+    engine sustained inside the timed region itself (the step also holds the non-conv kernels)."""
     from face_crop_plus_amd import engine as E
+    timed_streams = p.det.streams
     if not live:
         saved, p.det.streams = p.det.streams, 1
         graphed, p.graphed = p.graphed, None          # per-launch events need the eager launches
@@ -272,38 +288,119 @@ def conv_roofline(p: Pipeline, nsteps, live):
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
     split = p.precision == "f16x3"
     peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-    traffic, traffic_src = None, None
-    pdir = os.path.join(ROOT, "profiles")
-    prof = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_conv.json")) if os.path.isdir(pdir) else []
-    prof = [f for f in prof if ("f16x3" in f) == split]
-    if prof and not p.full and p.batch == 64 and p.size == 640:
-        with open(os.path.join(pdir, prof[-1])) as f:
-            traffic = round(json.load(f)["hbm_bytes_per_launch"])
-        traffic_src = "profiles/" + prof[-1]
-    return {"bound": "mfma",
-            "kernel": ("conv_igemm_f16x3 family (3x v_mfma_f32_32x32x16_f16 per product: x = hi + lo split)" if split
-                       else "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)"),
-            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            # the split path executes 3 matrix FLOP per algorithmic FLOP: utilisation of the f16 pipe
-            "executed_frac": round(achieved * (3 if split else 1) / peak, 4),
-            "traffic": traffic,
-            "traffic_unit": "HBM bytes per conv launch (PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
-            "traffic_source": traffic_src,
-            # PMC counters cannot be read from inside the process: `traffic` is the committed rocprofv3 --pmc
-            # measurement of this same command, not a value measured in this run
-            "traffic_static": traffic is not None,
-            "measured": ("HIP events around every conv launch of the timed steps" if live else
-                         f"HIP events around every conv launch of {nsteps} single-stream passes over the batch right "
-                         f"after the timed region"),
-            "launches_per_step": launches, "algorithmic_gflop_per_step": round(conv_flops / 1e9, 2),
-            "avg_launch_ms": round(conv_ms / launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
+    traffic, traffic_src = _pmc_traffic(traffic_key) if traffic_key else (None, None)
+    rec = {"bound": "mfma",
+           "kernel": ("conv_igemm_f16x3 family (3x v_mfma_f32_32x32x16_f16 per product: x = hi + lo split)" if split
+                      else "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)"),
+           "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+           # the split path executes 3 matrix FLOP per algorithmic FLOP: utilisation of the f16 pipe
+           "executed_frac": round(achieved * (3 if split else 1) / peak, 4),
+           "streams": 1,
+           "traffic": traffic,
+           "traffic_unit": "HBM bytes per conv launch (PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+           "traffic_source": traffic_src,
+           # PMC counters cannot be read from inside the process: `traffic` is the committed rocprofv3 --pmc
+           # measurement of this same command, not a value measured in this run
+           "traffic_static": traffic is not None,
+           "measured": ("HIP events around every conv launch of the timed steps" if live else
+                        f"HIP events around every conv launch of {nsteps} single-stream passes over the batch right "
+                        f"after the timed region"),
+           "launches_per_step": launches, "algorithmic_gflop_per_step": round(conv_flops / 1e9, 2),
+           "avg_launch_ms": round(conv_ms / launches, 4), "conv_ms_per_step": round(conv_ms, 3)}
+    if timed_ms is not None:
+        timed = conv_flops / (timed_ms * 1e-3) / 1e12
+        rec.update(achieved_timed=round(timed, 2), frac_timed=round(timed / peak, 4), timed_streams=timed_streams,
+                   timed_note=f"algorithmic conv FLOP of a step / ms_per_step of the timed region ({timed_streams} detector "
+                              f"stream(s); the step also contains the non-conv kernels, so this is a lower bound); "
+                              f"`achieved` / `frac` come from per-launch events of single-stream passes")
+    return rec
+
+
+def hbm_kernel_records(p: Pipeline, reps=20):
+    """HBM-bound (non-conv) kernels of the step, each timed alone with HIP events on the launch stream over `reps`
+    back-to-back launches on the tensors of the last step: SURVEY.md 8(d) "HBM GB/s for the non-conv kernels".
+    bytes = algorithmic bytes, peak = 8 TB/s (MI355X_MICROARCH.md)."""
+    from face_crop_plus_amd import _native as N, retinaface as RF, align
+    res, crops, ok = p.last
+    det, dev = p.det, p.dev
+    n, h, w = p.images.shape[:3]
+    heads = res["heads"]
+    P = res["cand_score"].shape[1]
+    lib, st = N.lib(), N.stream_ptr()
+    nf = min(int(res["face_offset"][-1].item()), res["max_faces"])
+    ncand = int(res["cand_count"].sum().item())
+    f = res["landmarks"].shape[0]
+    oh = ow = p.out_size
+    ws = torch.empty((int(lib.fcp_retina_nms_workspace_bytes(n, P)),), dtype=torch.uint8, device=dev)
+    mat = torch.empty((f, 6), dtype=torch.float64, device=dev)
+    okb = torch.empty((f,), dtype=torch.int32, device=dev)
+    pads = getattr(p, "pads", None)
+
+    def decode():
+        N.check(lib.fcp_retina_decode(heads[0].ptr(), heads[1].ptr(), heads[2].ptr(), n, h, w, float(det.vis_threshold),
+                                      float(det.variance[0]), float(det.variance[1]), N.ptr(res["cand_score"]),
+                                      N.ptr(res["cand_box"]), N.ptr(res["cand_ldm"]), N.ptr(res["cand_prior"]),
+                                      N.ptr(res["cand_count"]), None, None, None, st))
+
+    def nms():
+        N.check(lib.fcp_retina_nms_select(N.ptr(res["cand_score"]), N.ptr(res["cand_box"]), N.ptr(res["cand_count"]), n, P,
+                                          float(det.nms_threshold), RF.STRATEGIES[det.strategy], N.ptr(ws),
+                                          N.ptr(res["keep_pos"]), N.ptr(res["keep_count"]), N.ptr(res["sel_pos"]),
+                                          N.ptr(res["sel_count"]), st))
+
+    def gather():
+        N.check(lib.fcp_retina_gather_faces(N.ptr(res["cand_ldm"]), N.ptr(res["sel_pos"]), N.ptr(res["sel_count"]), n, P,
+                                            N.ptr(pads), f, N.ptr(res["face_offset"]), N.ptr(res["landmarks"]),
+                                            N.ptr(res["img_idx"]), st))
+
+    def estimate():
+        N.check(lib.fcp_estimate_transform_counted(N.ptr(res["landmarks"]), N.ptr(p.tgt), f, 5, 0, N.ptr(res["face_offset"][-1:]),
+                                                   N.ptr(mat), N.ptr(okb), None, st))
+
+    def warp():
+        N.check(lib.fcp_warp_affine_u8(N.ptr(p.images), n, h, w, N.ptr(res["img_idx"]), N.ptr(mat), N.ptr(okb), N.ptr(pads),
+                                       f, oh, ow, 0, N.ptr(crops), st))
+
+    estimate()
+    torch.cuda.synchronize()
+    m = mat[:max(nf, 1)].cpu().numpy().reshape(-1, 6)
+    det2 = np.abs(m[:, 0] * m[:, 4] - m[:, 1] * m[:, 3])
+    src_px = np.minimum(np.where(det2 > 0, oh * ow / np.maximum(det2, 1e-30), 0.0), h * w)   # source footprint per face
+    work = {   # kernel -> (fn, algorithmic bytes per launch, what they are)
+        "retina_decode_kernel": (decode, n * P * 16 * 4 + ncand * (4 + 16 + 40 + 4),
+                                 "16 fp32 head values per prior read + compacted candidates written"),
+        "retina_nms_kernel": (nms, ncand * (4 + 16) * 2 + ncand * 8,
+                              "candidate scores + boxes read, sorted keys / boxes written once (latency / LDS bound)"),
+        "retina_gather_kernel": (gather, n * 4 * 2 + nf * (40 + 4) * 2, "selected landmarks gathered (launch-latency bound)"),
+        "estimate_transform_kernel": (estimate, f * (40 + 48 + 4), "5 points in, 2x3 f64 + flag out (launch-latency bound)"),
+        "warp_affine_kernel<4>": (warp, nf * oh * ow * 3 + int(src_px.sum()) * 3,
+                                  "crop bytes written + source footprint (crop area / |det M|) read once"),
+    }
+    out = {}
+    for name, (fn, nbytes, what) in work.items():
+        fn(); fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out[name] = {"bound": "hbm", "avg_launch_us": round(ms * 1e3, 2), "bytes": int(nbytes), "bytes_are": what,
+                     "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4)}
+    out["_note"] = (f"{reps} back-to-back launches each, HIP events on the launch stream, tensors of the last timed step "
+                    f"(n={n}, P={P}, {ncand} candidates, {nf} faces); back-to-back launches include the ~1.5 us "
+                    f"dependent-launch boundary")
+    return out
 
 
 def run_extra(dev, sds, args):
     """The other configurations, one GPU, measured like the headline (same Pipeline / timing / roofline code)."""
     out = {}
 
-    def one(key, note, steps, warmup, cls=Pipeline, **kw):
+    def one(key, note, steps, warmup, cls=Pipeline, traffic_key=None, hbm=False, **kw):
         try:
             if cls is Pipeline:
                 kw["strategy"] = args.strategy
@@ -318,7 +415,10 @@ def run_extra(dev, sds, args):
             if cls is Pipeline4K:
                 rec["faces_per_frame"] = round(int(faces.item()) / steps / p.batch, 2)
                 rec["frames_per_s"] = round(p.batch * steps / elapsed, 2)
-            rec["roofline"] = conv_roofline(p, 1 if p.enh is not None else 2, live=False)
+            rec["roofline"] = conv_roofline(p, 1 if p.enh is not None else 2, live=False,
+                                            timed_ms=elapsed / steps * 1e3, traffic_key=traffic_key)
+            if hbm:
+                rec["hbm_kernels"] = hbm_kernel_records(p)
             out[key] = rec
             del p
         except Exception as e:                           # an extra must never take the headline line down
@@ -328,17 +428,21 @@ def run_extra(dev, sds, args):
 
     from face_crop_plus_amd import weights
     sds = dict(sds, rrdb=weights.generate_state_dict("rrdb"), bisenet=weights.generate_state_dict("bisenet"))
+    one("c3_detect_align_crop_1024", "the north-star metric at the north-star geometry: detect + align + crop (no parse, no "
+        "RRDB) on batch 32 @1024x1024 — the per-GPU rate that decides >= 10 k faces/s on 8 GPUs (needs >= 1250)", 10, 3,
+        full=False, batch=32, size=1024, precision="f16x3", enhance="none", traffic_key="c3det_pmc", hbm=True)
     one("c3_full_no_enhance", "BASELINE configs[2] without enhancement: detect + align + BiSeNet parse", 5, 2,
-        full=True, batch=32, size=1024, precision="f16x3", enhance="none")
+        full=True, batch=32, size=1024, precision="f16x3", enhance="none", traffic_key="c3_pmc")
     one("c3_full_enhance_all", "configs[2] with RRDB on EVERY image (worst case), batch reduced to 2: the enhancer "
-        "costs ~37.6 TFLOP per 1024x1024 image", 2, 1, full=True, batch=2, size=1024, precision="f16x3", enhance="all")
+        "costs ~37.6 TFLOP per 1024x1024 image", 2, 1, full=True, batch=2, size=1024, precision="f16x3", enhance="all",
+        traffic_key="rrdb_pmc")
     one("c3_full_enhance_rule", "configs[2] with the reference's face-area gate (rrdb.py:124-140), batch 8", 2, 1,
         full=True, batch=8, size=1024, precision="f16x3", enhance="rule")
     one("c5_4k_all", "BASELINE configs[4] on one GPU: 4K frames, strategy=all, RRDB by the reference's gate; the frame "
         "decode / H2D is outside the timed region, the resize + pad batch builder inside", 2, 1, cls=Pipeline4K,
         batch=4, precision="f16x3")
     one("c2_detect_f32", "headline workload in the exact-fp32 mode (v_mfma_f32_32x32x2_f32, peak 157.3 TFLOP/s)", 5, 2,
-        full=False, batch=64, size=640, precision="f32", enhance="none")
+        full=False, batch=64, size=640, precision="f32", enhance="none", traffic_key="f32_pmc_conv")
     return out
 
 
@@ -387,8 +491,14 @@ def main():
     total_faces = int(faces.item())
 
     roofline = cpu_baseline = extra = None
+    hbm_kernels = None
     if rank == 0:
-        roofline = conv_roofline(p, args.steps if live else args.roofline_steps, live)
+        std = not full and args.batch == 64 and args.size == 640
+        key = ("f16x3_pmc_conv" if args.precision == "f16x3" else "f32_pmc_conv") if std else None
+        roofline = conv_roofline(p, args.steps if live else args.roofline_steps, live,
+                                 timed_ms=elapsed / args.steps * 1e3, traffic_key=key)
+        if not args.graph:
+            hbm_kernels = hbm_kernel_records(p)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(sd, p.images[:32].cpu(), args, p.tgt.cpu().numpy())
     describe = p.describe()
@@ -411,7 +521,7 @@ def main():
                        "global_batch": args.batch * world, "image_size": args.size, "parallelism": f"dp{world}",
                        "faces_per_step": total_faces / max(args.steps, 1),
                        "images_per_s": round(args.batch * world * args.steps / elapsed, 2)},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "hbm_kernels": hbm_kernels, "cpu_baseline": cpu_baseline,
         }
         if extra is not None:
             line["extra"] = extra

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_f32p = C.c_void_p
 _lib = None
@@ -63,6 +63,7 @@ SIGNATURES = {
     "fcp_retina_nms_select": [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
     "fcp_retina_gather_faces": [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P],
     "fcp_estimate_transform": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "fcp_estimate_transform_counted": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "fcp_bise_preprocess_u8": [_P, _I, _I, _I, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P],
     "fcp_avgpool_nhwc_f32": [_P, _I, _I, _I, _I, _P, _P],
     "fcp_fc_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],

@@ -28,17 +28,22 @@ def border_code(padding: str) -> int:
     return BORDER_MODES[key]
 
 
-def estimate_transform(landmarks: torch.Tensor, target: torch.Tensor, allow_skew: bool = False):
-    """landmarks (F,k,2) f32 device, target (k,2) f32 device -> (mat (F,6) f64, ok (F,) i32)."""
+def estimate_transform(landmarks: torch.Tensor, target: torch.Tensor, allow_skew: bool = False,
+                       face_count: torch.Tensor | None = None, valid_total: torch.Tensor | None = None):
+    """landmarks (F,k,2) f32 device, target (k,2) f32 device -> (mat (F,6) f64, ok (F,) i32).
+    ``face_count``: device int32 scalar (view), live rows of a fixed-capacity face array — rows beyond it get ok = 0;
+    ``valid_total``: device int64 scalar the number of ok faces is added to (both optional, no host read-back)."""
     f, k = landmarks.shape[0], landmarks.shape[1]
     dev = landmarks.device
     if T.ENABLED:
-        mat, ok = T.load().similarity_from_5pt(landmarks.contiguous(), target.contiguous(), bool(allow_skew))
+        mat, ok = T.load().similarity_from_5pt(landmarks.contiguous(), target.contiguous(), bool(allow_skew), face_count,
+                                               valid_total)
         return mat.view(f, 6), ok
     mat = torch.empty((f, 6), dtype=torch.float64, device=dev)
     ok = torch.empty((f,), dtype=torch.int32, device=dev)
-    N.check(N.lib().fcp_estimate_transform(N.ptr(landmarks.contiguous()), N.ptr(target.contiguous()), f, k,
-                                           int(bool(allow_skew)), N.ptr(mat), N.ptr(ok), N.stream_ptr()),
+    N.check(N.lib().fcp_estimate_transform_counted(N.ptr(landmarks.contiguous()), N.ptr(target.contiguous()), f, k,
+                                                   int(bool(allow_skew)), N.ptr(face_count), N.ptr(mat), N.ptr(ok),
+                                                   N.ptr(valid_total), N.stream_ptr()),
             "fcp_estimate_transform")
     return mat, ok
 
@@ -59,9 +64,11 @@ def warp_affine(images_u8: torch.Tensor, img_idx: torch.Tensor, mat: torch.Tenso
     return out
 
 
-def crop_align(images_u8, img_idx, landmarks, target, output_size, border=0, allow_skew=False, paddings=None):
+def crop_align(images_u8, img_idx, landmarks, target, output_size, border=0, allow_skew=False, paddings=None,
+               face_count=None, valid_total=None):
     """Device crop_align: -> (crops (F,oh,ow,3) u8, ok (F,) i32, mat (F,6) f64).  Faces
-    with ok == 0 (degenerate transform) are dropped by the caller like cropper.py:529-531."""
+    with ok == 0 (degenerate transform) are dropped by the caller like cropper.py:529-531.
+    ``face_count`` / ``valid_total``: see ``estimate_transform``."""
     dev = images_u8.device
     landmarks = landmarks.to(device=dev, dtype=torch.float32)
     if not isinstance(target, torch.Tensor):
@@ -70,6 +77,6 @@ def crop_align(images_u8, img_idx, landmarks, target, output_size, border=0, all
     img_idx = img_idx.to(device=dev, dtype=torch.int32).contiguous()
     if paddings is not None:
         paddings = paddings.to(device=dev, dtype=torch.int32).contiguous()
-    mat, ok = estimate_transform(landmarks, target, allow_skew)
+    mat, ok = estimate_transform(landmarks, target, allow_skew, face_count, valid_total)
     crops = warp_affine(images_u8, img_idx, mat, ok, paddings, output_size, border)
     return crops, ok, mat

@@ -67,7 +67,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    build_torch_ops(force, verbose)
+    # The TORCH_LIBRARY veneer is optional (default boundary: see torch_ops.py): a host without a matching g++ / torch
+    # headers must still get the C-ABI library; torch_ops.load() raises lazily when the file is missing.
+    try:
+        build_torch_ops(force, verbose)
+    except Exception as e:                                  # noqa: BLE001 - compiler / header / ABI problems alike
+        import warnings
+        warnings.warn(f"libfcp_torch.so (torch.ops.fcp veneer) was not built: {e}")
     return LIB
 
 

@@ -186,20 +186,27 @@ class Cropper:
         """Write one file: inline, or — inside process_dir — as a task on the I/O pool.  At most
         MAX_PENDING_WRITES tasks are in flight: a slow disk stalls the GPU worker here instead of piling uint8
         crops up in host memory, and a failed write surfaces at the next batch, not at the end of the run."""
-        if self._writer is None:
+        # Locals: process_dir resets the attributes when it unwinds, while tasks of a failed run may still be in flight.
+        writer = getattr(self, "_writer", None)
+        writes, slots = getattr(self, "_writes", None), getattr(self, "_write_slots", None)
+        if writer is None:
             write_image(path, pixels)
             return
-        self._write_slots.acquire()
+        slots.acquire()
 
         def task():
             try:
                 write_image(path, pixels)
             finally:
-                self._write_slots.release()
+                slots.release()
         with self._write_lock:
-            done = [w for w in self._writes if w.done()]
-            self._writes[:] = [w for w in self._writes if not w.done()]
-            self._writes.append(self._writer.submit(task))
+            done = [w for w in writes if w.done()]
+            writes[:] = [w for w in writes if not w.done()]
+            try:
+                writes.append(writer.submit(task))
+            except BaseException:
+                slots.release()          # the task will never run: give its slot back
+                raise
         for w in done:
             w.result()               # re-raise an encode / write error of an earlier file now
 
@@ -383,5 +390,5 @@ class Cropper:
             for w in self._writes:
                 w.result()                       # surface encode / write errors
         finally:
+            io.shutdown(wait=True)       # in-flight tasks still hold the semaphore / list: reset only afterwards
             self._writer, self._writes, self._write_slots = None, None, None
-            io.shutdown(wait=True)

@@ -56,3 +56,17 @@ static inline int fcp_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
       _mask.fetch_or(_bit, std::memory_order_release);                                             \
     }                                                                                              \
   } while (0)
+
+// Compute units of the current device, cached per device ordinal (a process may drive several GPUs).
+static inline int fcp_cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::atomic<int>& slot = cache[dev & 63];
+  int n = slot.load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    slot.store(n, std::memory_order_relaxed);
+  }
+  return n;
+}

@@ -449,14 +449,7 @@ int launch_f16x3_halo(const ConvK& k, hipStream_t s) {
   const size_t lds = (size_t)LDS_TOTAL;
   const long tiles = (long)k.n * ((k.out_h + TH - 1) / TH) * ((k.out_w + TW - 1) / TW);
   FCP_REQUIRE(tiles < (1L << 31), "conv(halo): too many tiles");
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    FCP_HIP_OK(hipGetDevice(&dev));
-    FCP_HIP_OK(hipGetDeviceProperties(&prop, dev));
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int cus = fcp_cu_count();
   const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
   if (k.cout <= 32) {
     FCP_LDS_OPT_IN(&conv3x3_halo_f16x3<1>, lds);

@@ -326,29 +326,44 @@ __global__ void __launch_bounds__(NMS_THREADS) retina_nms_kernel(
   }
 }
 
-__global__ void __launch_bounds__(256) retina_gather_kernel(
+// One workgroup (a single wave) per image: its face offset is the sum of the selection counts of the images before it
+// (n is a batch size: a wave-strided read + a 64-lane reduction), so no block waits for another.  The blocks also clear
+// the unused tail [total, max_faces) of the outputs between them — callers need no memset — and block n-1 publishes the
+// total in face_offset[n].
+__global__ void __launch_bounds__(64) retina_gather_kernel(
     const float* __restrict__ cand_ldm, const int* __restrict__ sel_pos, const int* __restrict__ sel_count,
     int n, int cap, const int* __restrict__ paddings, int max_faces, int* __restrict__ face_offset,
     float* __restrict__ out_ldm, int* __restrict__ out_img) {
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int i = 0; i < n; ++i) { face_offset[i] = acc; acc += sel_count[i]; }
-    face_offset[n] = acc;
+  const int img = blockIdx.x, lane = threadIdx.x;
+  int before = 0, all = 0;
+  for (int i = lane; i < n; i += 64) {
+    const int c = sel_count[i];
+    all += c;
+    before += i < img ? c : 0;
   }
-  __threadfence_block();
-  __syncthreads();
-  for (int img = 0; img < n; ++img) {
-    const int off = face_offset[img], cnt = sel_count[img];
-    const float px = paddings ? (float)paddings[img * 4 + 2] : 0.f;  // left
-    const float py = paddings ? (float)paddings[img * 4 + 0] : 0.f;  // top
-    for (int e = threadIdx.x; e < cnt * 10; e += blockDim.x) {
-      const int k = e / 10, c = e - k * 10;
-      const int face = off + k;
-      if (face >= max_faces) continue;
-      const float v = cand_ldm[((long)img * cap + sel_pos[(long)img * cap + k]) * 10 + c];
-      out_ldm[(long)face * 10 + c] = v - ((c & 1) ? py : px);
-      if (c == 0) out_img[face] = img;
-    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    before += __shfl_xor(before, o);
+    all += __shfl_xor(all, o);
+  }
+  const int off = before, cnt = sel_count[img];
+  if (lane == 0) {
+    face_offset[img] = off;
+    if (img == n - 1) face_offset[n] = all;
+  }
+  const float px = paddings ? (float)paddings[img * 4 + 2] : 0.f;  // left
+  const float py = paddings ? (float)paddings[img * 4 + 0] : 0.f;  // top
+  for (int e = lane; e < cnt * 10; e += 64) {
+    const int k = e / 10, c = e - k * 10;
+    const int face = off + k;
+    if (face >= max_faces) break;                                   // e is increasing per lane: nothing further fits
+    const float v = cand_ldm[((long)img * cap + sel_pos[(long)img * cap + k]) * 10 + c];
+    out_ldm[(long)face * 10 + c] = v - ((c & 1) ? py : px);
+    if (c == 0) out_img[face] = img;
+  }
+  for (long face = (long)all + img; face < max_faces; face += n) {   // unused tail: zero, shared out over the blocks
+    if (lane < 10) out_ldm[face * 10 + lane] = 0.f;
+    if (lane == 10) out_img[face] = 0;
   }
 }
 
@@ -411,7 +426,7 @@ extern "C" int fcp_retina_gather_faces(const float* cand_ldm, const int32_t* sel
                                        int32_t* out_img, fcp_stream_t stream) {
   FCP_REQUIRE(cand_ldm && sel_pos && sel_count && face_offset && out_ldm && out_img, "retina_gather: null pointer");
   FCP_REQUIRE(n > 0 && cap > 0 && max_faces > 0, "retina_gather: bad sizes");
-  hipLaunchKernelGGL(retina_gather_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cand_ldm, sel_pos,
+  hipLaunchKernelGGL(retina_gather_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, cand_ldm, sel_pos,
                      sel_count, n, cap, paddings, max_faces, face_offset, out_ldm, out_img);
   FCP_LAUNCH_OK();
   return 0;

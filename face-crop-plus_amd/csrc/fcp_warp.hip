@@ -16,14 +16,30 @@
 
 namespace {
 
+__device__ __forceinline__ bool estimate_one(const float* __restrict__ src, const float* __restrict__ dst, int i, int k,
+                                             int allow_skew, bool is_live, double* __restrict__ mat, int* __restrict__ ok);
+
 __global__ void __launch_bounds__(64) estimate_transform_kernel(const float* __restrict__ src,
                                                                 const float* __restrict__ dst, int f, int k,
                                                                 int allow_skew, double* __restrict__ mat,
-                                                                int* __restrict__ ok) {
+                                                                int* __restrict__ ok,
+                                                                const int* __restrict__ face_count,
+                                                                long long* __restrict__ valid_total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= f) return;
+  const int live = face_count != nullptr ? min(*face_count, f) : f;   // rows >= live are padding of a fixed-size batch
+  bool counted = false;
+  if (i < f) counted = estimate_one(src, dst, i, k, allow_skew, i < live, mat, ok);
+  if (valid_total != nullptr) {                                        // whole wave gets here: one atomic per wave
+    const unsigned long long votes = __ballot(counted);
+    if ((threadIdx.x & 63) == 0 && votes != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(valid_total), (unsigned long long)__popcll(votes));
+  }
+}
+
+// One face: returns whether it is a valid (live, non-degenerate) face; writes its matrix and ok flag.
+__device__ __forceinline__ bool estimate_one(const float* __restrict__ src, const float* __restrict__ dst, int i, int k,
+                                             int allow_skew, bool is_live, double* __restrict__ mat, int* __restrict__ ok) {
   const float* s = src + (long)i * k * 2;
-  bool finite = true;
+  bool finite = is_live;
   double mx = 0, my = 0, MX = 0, MY = 0;
   for (int p = 0; p < k; ++p) {
     const double x = s[2 * p], y = s[2 * p + 1];
@@ -70,6 +86,7 @@ __global__ void __launch_bounds__(64) estimate_transform_kernel(const float* __r
   for (int q = 0; q < 6; ++q) good = good && isfinite(m[q]);
   for (int q = 0; q < 6; ++q) mat[(long)i * 6 + q] = good ? m[q] : 0.0;
   ok[i] = good ? 1 : 0;
+  return good;
 }
 
 // cv::saturate_cast<int>(double) == cvRound (cvtsd2si: nearest-even, 0x80000000 when out of range)
@@ -192,14 +209,20 @@ __global__ void __launch_bounds__(256) warp_affine_kernel(
 
 }  // namespace
 
-extern "C" int fcp_estimate_transform(const float* src, const float* dst, int f, int k, int allow_skew,
-                                      double* mat, int32_t* ok, fcp_stream_t stream) {
+extern "C" int fcp_estimate_transform_counted(const float* src, const float* dst, int f, int k, int allow_skew,
+                                              const int32_t* face_count, double* mat, int32_t* ok,
+                                              int64_t* valid_total, fcp_stream_t stream) {
   FCP_REQUIRE(src && dst && mat && ok, "estimate_transform: null pointer");
   FCP_REQUIRE(f > 0 && k >= 2 && k <= 128, "estimate_transform: bad sizes (f=%d, k=%d)", f, k);
   hipLaunchKernelGGL(estimate_transform_kernel, dim3(fcp_cdiv(f, 64)), dim3(64), 0, (hipStream_t)stream, src,
-                     dst, f, k, allow_skew, mat, ok);
+                     dst, f, k, allow_skew, mat, ok, face_count, reinterpret_cast<long long*>(valid_total));
   FCP_LAUNCH_OK();
   return 0;
+}
+
+extern "C" int fcp_estimate_transform(const float* src, const float* dst, int f, int k, int allow_skew,
+                                      double* mat, int32_t* ok, fcp_stream_t stream) {
+  return fcp_estimate_transform_counted(src, dst, f, k, allow_skew, nullptr, mat, ok, nullptr, stream);
 }
 
 extern "C" int fcp_warp_affine_u8(const uint8_t* images, int n, int h, int w, const int32_t* img_idx,

@@ -312,17 +312,20 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
             # Tuning launches the op several times.  An op whose output aliases one of its inputs (RRDB's last dense-block
             # conv writes the buffer its second residual is read from) is not idempotent: its trial launches write a
             # scratch tensor of the same geometry instead, and only the final launch below touches the real output.
-            real_out = d.out
-            aliased = any(t is not None and t.buf.untyped_storage().data_ptr() == out.buf.untyped_storage().data_ptr()
-                          for t in (x, x2, res1, res2))
-            scratch = torch.empty_like(out.buf) if aliased else None
+            # Only a real overlap counts: reading and writing disjoint channel slices of one buffer (RRDB's dense-block
+            # convs, SSH's concat) is idempotent.  The scratch holds just the output view (its own pixel pitch), not a
+            # copy of the whole buffer.
+            real_out, real_ld = d.out, d.out_ld
+            same = lambda t: t is not None and t.buf.untyped_storage().data_ptr() == out.buf.untyped_storage().data_ptr()
+            aliased = any(same(t) and t.c0 < out.c0 + out.c and out.c0 < t.c0 + t.c for t in (x, x2, res1, res2))
+            scratch = torch.empty((out.n, out.h, out.w, out.c), dtype=torch.float32, device=out.buf.device) if aliased else None
 
             def _launch(t):
                 d.tile_m, d.tile_n = t
                 if scratch is not None:
-                    d.out = N.ptr(scratch, 4 * out.c0)
+                    d.out, d.out_ld = N.ptr(scratch), out.c
                 N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
-                d.out = real_out
+                d.out, d.out_ld = real_out, real_ld
             cands = [(128, 64), (128, 128)]
             if halo_ok:
                 cands = ([(128, 32)] if pc.cout <= 32 else []) + [(128, 64), (1, 32)]
@@ -336,13 +339,13 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    if T.ENABLED:            # FCP_BOUNDARY=torch: the same launch through the registered PyTorch custom op
-        T.load().conv2d(x.buf, x.c0, pc.cin, pc.w, pc.bias, pc.wscale, None if res1 is None else res1.buf,
-                        0 if res1 is None else res1.c0, None if res2 is None else res2.buf, 0 if res2 is None else res2.c0,
-                        out.buf, out.c0, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, float(act_slope), float(alpha), float(alpha2),
-                        bool(res1_pre), pc.precision, x.fmt, out.fmt, d.res1_fmt, d.res2_fmt, bool(in_up2), bool(pc.cin4),
-                        int(d.tile_m), int(d.tile_n), None if x2 is None else x2.buf, 0 if x2 is None else x2.c0,
-                        0 if x2 is None else x2.c, int(x2_stride), int(d.flags))
+    if T.ENABLED:            # FCP_BOUNDARY=torch: the same launch through the registered PyTorch custom op (out variant)
+        T.load().conv2d_out(x.buf, x.c0, pc.cin, pc.w, pc.bias, pc.wscale, None if res1 is None else res1.buf,
+                            0 if res1 is None else res1.c0, None if res2 is None else res2.buf, 0 if res2 is None else res2.c0,
+                            out.buf, out.c0, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, float(act_slope), float(alpha), float(alpha2),
+                            bool(res1_pre), pc.precision, x.fmt, out.fmt, d.res1_fmt, d.res2_fmt, bool(in_up2), bool(pc.cin4),
+                            int(d.tile_m), int(d.tile_n), None if x2 is None else x2.buf, 0 if x2 is None else x2.c0,
+                            0 if x2 is None else x2.c, int(x2_stride), int(d.flags))
     else:
         N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
     if timing is not None:

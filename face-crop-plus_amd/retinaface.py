@@ -175,6 +175,8 @@ class RetinaFace:
             x = E.conv(blk["c3"], o, act_slope=0.0, res1=idt, res1_pre=True, out_fmt=f)
             if blk["feat"]:
                 feats.append(x)
+        if getattr(self, "_debug_feats", None) is not None:      # tests: the body's three feature maps (layer2..4)
+            self._debug_feats.extend(feats)
         # FPN (_layers.py:127-145): LeakyReLU slope 0 == ReLU for 256 channels
         o3 = E.conv(p["fpn.output3"], feats[2], act_slope=0.0, out_fmt=f)
         o2 = E.conv(p["fpn.output2"], feats[1], act_slope=0.0, res1=o3, res1_pre=False, out_fmt=f)
@@ -271,8 +273,8 @@ class RetinaFace:
         if max_faces is None:
             max_faces = n if self.strategy != "all" else int(out["sel_count"].sum().item())
         max_faces = max(int(max_faces), 1)
-        landmarks = torch.zeros((max_faces, 5, 2), dtype=f32, device=dev)
-        img_idx = torch.zeros((max_faces,), dtype=i32, device=dev)
+        landmarks = torch.empty((max_faces, 5, 2), dtype=f32, device=dev)     # the gather kernel zeroes the unused tail
+        img_idx = torch.empty((max_faces,), dtype=i32, device=dev)
         face_offset = torch.empty((n + 1,), dtype=i32, device=dev)
         if paddings is not None:
             paddings = paddings.to(device=dev, dtype=i32).contiguous()

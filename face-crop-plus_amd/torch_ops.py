@@ -33,5 +33,5 @@ def load():
     return torch.ops.fcp
 
 
-OPS = ("conv2d", "bottleneck_chain", "retina_decode", "nms_select", "gather_faces", "similarity_from_5pt",
+OPS = ("conv2d", "conv2d_out", "bottleneck_chain", "retina_decode", "nms_select", "gather_faces", "similarity_from_5pt",
        "warp_affine_u8", "bicubic_down4_round", "parse_argmax_hist")

@@ -166,12 +166,20 @@ _ENCODER_KW = {
 
 
 def write_image(path: str, image: np.ndarray) -> bool:
-    """RGB (or single-channel mask) uint8 array -> file; format from the extension, ``cv2.imwrite`` defaults.
-    An extension with no encoder warns and returns False (the file is skipped) instead of raising."""
+    """RGB (or single-channel mask) uint8 array -> file; format from the extension, ``cv2.imwrite`` defaults for the
+    formats listed above, Pillow's own choice of encoder for every other extension it knows (.ppm / .pgm / .pnm /
+    .jp2 / ... — ``cv2.imwrite`` writes these too).  Only an extension NO encoder exists for warns and returns False
+    (the file is skipped) instead of raising."""
     from PIL import Image
     kw = _ENCODER_KW.get(os.path.splitext(path)[1].lower())
-    if kw is None:
-        warnings.warn(f"Could not write the image {path}: no encoder for this extension")
+    if kw is not None:
+        Image.fromarray(image).save(path, **kw)
+        return True
+    try:
+        Image.fromarray(image).save(path)          # format inferred from the extension
+    except (ValueError, KeyError, OSError) as e:    # unknown extension / encoder plug-in not built into this Pillow
+        if os.path.exists(path) and os.path.getsize(path) == 0:
+            os.remove(path)
+        warnings.warn(f"Could not write the image {path}: {e}")
         return False
-    Image.fromarray(image).save(path, **kw)
     return True

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 10
+#define FCP_ABI_VERSION 11
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -231,8 +231,9 @@ int fcp_retina_nms_select(const float* cand_score, const float* cand_box,
 /* Gather the selected faces into dense, image-major arrays (the return value
  * of RetinaFace.predict, retinaface.py:465-470, minus the D2H copy) and apply
  * the landmark un-padding of cropper.py:822 (paddings (n,4) int32 t,b,l,r or NULL).
- * face_offset: (n+1) int32 exclusive prefix of sel_count (written here).
- * out_ldm (max_faces,5,2) f32, out_img (max_faces) int32. */
+ * face_offset: (n+1) int32 exclusive prefix of sel_count (written here;
+ * face_offset[n] = number of faces).  out_ldm (max_faces,5,2) f32, out_img
+ * (max_faces) int32: rows >= face_offset[n] are zeroed here (no memset needed). */
 int fcp_retina_gather_faces(const float* cand_ldm, const int32_t* sel_pos,
                             const int32_t* sel_count, int n, int cap,
                             const int32_t* paddings, int max_faces,
@@ -250,6 +251,17 @@ int fcp_retina_gather_faces(const float* cand_ldm, const int32_t* sel_pos,
  * (0 = degenerate / non-finite: the reference drops that face, cropper.py:529-531). */
 int fcp_estimate_transform(const float* src, const float* dst, int f, int k,
                            int allow_skew, double* mat, int32_t* ok, fcp_stream_t stream);
+
+/* The same for a fixed-capacity face array whose live length is on the device
+ * (the detector's face_offset[n]; RetinaFace.predict's `len(landmarks)`,
+ * retinaface.py:465-470): rows >= *face_count (device int32, or NULL = all f)
+ * get ok = 0 and a zero matrix, and the number of faces with ok = 1 — the faces
+ * crop_align keeps, cropper.py:529-531 — is ADDED to *valid_total (device
+ * int64 accumulator, or NULL).  No host read-back, no extra launches. */
+int fcp_estimate_transform_counted(const float* src, const float* dst, int f, int k,
+                                   int allow_skew, const int32_t* face_count,
+                                   double* mat, int32_t* ok, int64_t* valid_total,
+                                   fcp_stream_t stream);
 
 /* cv2.warpAffine(image, M, dsize, flags=INTER_LINEAR, borderMode) on the
  * un-padded slice of each face's batch image (cropper.py:533-547): OpenCV's

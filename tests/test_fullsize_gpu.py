@@ -138,8 +138,10 @@ def _photo_like(h, w, seed):
 
 def test_rrdb_c3_geometry_1024(device):
     """BASELINE configs[2] geometry for the enhancer: one real 1024x1024 image through RRDBNet.  At this size the
-    x4-resolution tail (HRconv / conv_last) reads a 64-channel tensor of 4 GiB, i.e. it takes the flat-addressing
-    fp32 kernel on its own.  The oracle needs ~90 s per image here, so the check is by properties: (i) the
+    x4-resolution tail (upconv2 / HRconv / conv_last, 64 channels at 4096x4096 = 4 GiB per tensor) runs in bands of
+    256 output rows on the fp16x3 kernels (``RRDBNet._tail``; bit-identical to one band over the whole image,
+    ``test_parse_enhance_gpu.py::test_rrdb_banded_tail_same_bits``), so no tensor of the pass reaches the 4 GiB limit of
+    buffer addressing.  The oracle needs ~90 s per image here, so the check is by properties: (i) the
     fp16x3 trunk agrees with the all-fp32 path within one rounding flip on < 0.2 % of the bytes, (ii) two runs are
     bit-identical, (iii) a 256x256 corner crop run alone agrees with the big run away from the crop's border
     (the network is translation equivariant; receptive field < 120 px)."""
@@ -216,3 +218,59 @@ def test_c3_full_pipeline_with_enhance(tmp_path, device):
         assert np.array_equal(got, crops[k]), f"crop of image {i} differs from the stage-by-stage result"
     masks = sorted(p.name for p in (tmp_path / "out" / "any" / "skin_mask").iterdir())
     assert masks == files
+
+
+def test_c5_rrdb_gated_leg(tmp_path, device):
+    """BASELINE configs[4]'s enhancement leg on letter-boxed 4K frames, strategy "all": the gate decision of the pipeline
+    equals the oracle's gate (rrdb.py:124-140) on the same landmarks — with a threshold placed BETWEEN the two frames'
+    face factors, so that exactly one frame is enhanced —, the batch the pipeline enhanced equals ``enh_model`` run stage
+    by stage, and the crops the pipeline hands to the writer are the oracle's estimate + warp of the enhanced bytes."""
+    from face_crop_plus_amd import Cropper, weights
+    from face_crop_plus_amd.batch import build_batch
+    from oracle import align_ref as A, batch_ref as B, rrdb_ref as RR
+    rng = np.random.default_rng(22)
+    base = rng.integers(0, 256, (270, 480, 3), dtype=np.uint8)
+    frames = [np.kron(base, np.ones((8, 8, 1), np.uint8)), rng.integers(0, 256, (2160, 3840, 3), dtype=np.uint8)]
+    w = {k: weights.generate_state_dict(k) for k in ("retinaface", "rrdb")}
+    c = Cropper(output_size=128, resize_size=1024, strategy="all", det_threshold=0.55, enh_threshold=0.001, device="cuda:0",
+                weights=w)
+    dev_batch, _, pads = build_batch(frames, c.resize_size, "constant", c.device)
+    _, _, epads = B.as_batch(frames, 1024)
+    assert pads.tolist() == epads.tolist() == [[224, 224, 0, 0]] * 2
+    for vis in (0.55, 0.8, 0.9, 0.95, 0.98, 0.99, 0.995, 0.999):          # K calibration as in bench.py's Pipeline4K
+        c.det_model.vis_threshold = vis
+        lm, idx = c.det_model.predict(dev_batch)
+        if len(idx) <= 24:
+            break
+    assert set(idx) == {0, 1} and 2 <= len(idx) <= 24, (vis, len(idx))
+    un = lm - pads[idx][:, None, [2, 0]].astype(np.float32)
+    idx = list(idx)
+    fac = [float(((un[np.array(idx) == i][:, 4, 0] - un[np.array(idx) == i][:, 0, 0]) *
+                  (un[np.array(idx) == i][:, 4, 1] - un[np.array(idx) == i][:, 0, 1]) / (1024 * 1024)).mean()) for i in (0, 1)]
+    assert fac[0] != fac[1]
+    thr = (fac[0] + fac[1]) / 2
+    c.enh_model.min_face_factor = thr
+    expect = RR.gate(un, idx, 2, 1024, 1024, thr)
+    assert c.enh_model.gate(2, 1024, 1024, un, idx) == expect and len(expect) == 1, (fac, expect)
+    # the pipeline itself (decoded frames in, writer intercepted)
+    seen = {}
+    enh_predict = c.enh_model.predict
+
+    def recording_predict(images, landmarks, indices):
+        out = enh_predict(images, landmarks, indices)
+        seen["enhanced"], seen["landmarks"], seen["indices"] = out.clone(), np.array(landmarks), list(indices)
+        return out
+    c.enh_model.predict = recording_predict
+    c.save_groups = lambda faces, names, out_dir, *groups: seen.update(faces=np.array(faces), names=list(names))
+    c._process_images(frames, np.array(["f0.png", "f1.png"]), str(tmp_path / "out"))
+    assert seen["indices"] == idx and np.array_equal(seen["landmarks"], un)
+    # stage by stage
+    staged = dev_batch.clone()
+    c.enh_model.enhance_u8(staged, expect)
+    torch.cuda.synchronize()
+    assert torch.equal(seen["enhanced"], staged), "the pipeline's enhanced batch differs from the stage-by-stage one"
+    other = 1 - expect[0]
+    assert torch.equal(staged[other], dev_batch[other]) and not torch.equal(staged[expect[0]], dev_batch[expect[0]])
+    ref = A.crop_align(staged.cpu().numpy(), epads, idx, un, A.landmarks_target((128, 128), 0.65), (128, 128), "constant")
+    assert seen["faces"].shape == ref.shape and np.array_equal(seen["faces"], ref), "crops != oracle warp of the enhanced bytes"
+    assert seen["names"] == [f"f{i}.png" for i in idx]

@@ -42,9 +42,49 @@ def test_png_webp_lossless_and_unknown_extension(tmp_path):
         assert write_image(str(tmp_path / name), arr)
         back = np.asarray(Image.open(tmp_path / name))
         assert np.array_equal(back, arr), name
-    with pytest.warns(UserWarning, match="no encoder"):
+    with pytest.warns(UserWarning, match="Could not write"):
         assert write_image(str(tmp_path / "a.xyz"), img) is False
     assert not (tmp_path / "a.xyz").exists()
+
+
+def test_extensions_outside_the_tuned_table_still_write(tmp_path):
+    """cv2.imwrite (cropper.py:605-609) also encodes .ppm / .pgm / .pnm / .jp2: an input of such a type, with
+    output_format=None, must produce an output file (Pillow picks the encoder from the extension)."""
+    from PIL import Image, features
+    from face_crop_plus_amd.utils import write_image
+    img = _smooth()
+    mask = (img[..., 0] > 127).astype(np.uint8) * 255
+    cases = [("a.ppm", img), ("m.pgm", mask), ("a.pnm", img)]
+    if features.check_codec("jpg_2000"):
+        cases.append(("a.jp2", img))
+    for name, arr in cases:
+        assert write_image(str(tmp_path / name), arr) is True, name
+        back = np.asarray(Image.open(tmp_path / name))
+        assert back.shape == arr.shape, name
+        if not name.endswith(".jp2"):
+            assert np.array_equal(back, arr), name
+
+
+def test_emit_after_process_dir_unwinds(tmp_path):
+    """A write task still in flight when process_dir's attributes are reset must finish (it holds its own references),
+    and a slot is given back when the executor refuses the task."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    import face_crop_plus_amd.cropper as CR
+    c = CR.Cropper.__new__(CR.Cropper)
+    c._writer, c._writes = ThreadPoolExecutor(2), []
+    c._write_slots, c._write_lock = threading.BoundedSemaphore(2), threading.Lock()
+    ex, writes, slots = c._writer, c._writes, c._write_slots
+    c._emit(str(tmp_path / "a.png"), np.zeros((2, 2, 3), np.uint8))
+    c._writer, c._writes, c._write_slots = None, None, None       # what process_dir's finally block does
+    for w in writes:
+        w.result()                                                 # no AttributeError inside the task
+    assert (tmp_path / "a.png").exists()
+    ex.shutdown(wait=True)
+    c._writer, c._writes, c._write_slots = ex, writes, slots
+    with pytest.raises(RuntimeError):                              # submit after shutdown
+        c._emit(str(tmp_path / "b.png"), np.zeros((2, 2, 3), np.uint8))
+    assert slots.acquire(blocking=False) and slots.acquire(blocking=False)     # both slots are free again
 
 
 def test_read_image_applies_exif_orientation(tmp_path):

@@ -149,3 +149,63 @@ def test_nms_empty_image_and_bad_strategy(device):
     assert out["keep_count"].tolist() == [0, 0] and out["sel_count"].tolist() == [0, 0]
     with pytest.raises(ValueError):
         nms_select(cs, cb, cc, 0.4, "biggest")
+
+
+@pytest.mark.parametrize("n,max_faces", [(1, 1), (5, 3), (7, 40), (64, 64), (200, 300)])
+def test_gather_faces_one_block_per_image(n, max_faces, device):
+    """``fcp_retina_gather_faces`` (one workgroup per image): image-major order, exclusive-prefix offsets, un-padding
+    (cropper.py:822), truncation at ``max_faces`` and a ZEROED tail — against a plain numpy restatement."""
+    from face_crop_plus_amd import _native as N
+    rng = np.random.default_rng(n * 131 + max_faces)
+    cap = 50
+    ldm = rng.normal(0, 100, (n, cap, 10)).astype(np.float32)
+    cnt = rng.integers(0, 4, n).astype(np.int32)
+    if n > 2:
+        cnt[1] = 0
+    pos = np.stack([rng.permutation(cap) for _ in range(n)]).astype(np.int32)
+    pads = rng.integers(0, 9, (n, 4)).astype(np.int32)
+    t = lambda a: torch.from_numpy(a).to(device)
+    d_ldm, d_pos, d_cnt, d_pad = t(ldm), t(pos), t(cnt), t(pads)
+    off = torch.full((n + 1,), -7, dtype=torch.int32, device=device)
+    out_l = torch.full((max_faces, 5, 2), float("nan"), device=device)
+    out_i = torch.full((max_faces,), -7, dtype=torch.int32, device=device)
+    N.check(N.lib().fcp_retina_gather_faces(N.ptr(d_ldm), N.ptr(d_pos), N.ptr(d_cnt), n, cap, N.ptr(d_pad), max_faces,
+                                            N.ptr(off), N.ptr(out_l), N.ptr(out_i), N.stream_ptr()))
+    torch.cuda.synchronize()
+    exp_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    exp_l = np.zeros((max_faces, 5, 2), np.float32)
+    exp_i = np.zeros((max_faces,), np.int32)
+    f = 0
+    for i in range(n):
+        for k in range(cnt[i]):
+            if f < max_faces:
+                exp_l[f] = ldm[i, pos[i, k]].reshape(5, 2) - pads[i, [2, 0]].astype(np.float32)
+                exp_i[f] = i
+            f += 1
+    assert np.array_equal(off.cpu().numpy(), exp_off)
+    assert np.array_equal(out_l.cpu().numpy(), exp_l) and np.array_equal(out_i.cpu().numpy(), exp_i)
+
+
+def test_estimate_transform_counted(device):
+    """``fcp_estimate_transform_counted``: rows beyond the device-side face count get ok = 0 / a zero matrix, live rows
+    equal the plain entry point bit for bit, and the number of kept faces is ADDED to the device accumulator."""
+    from face_crop_plus_amd import align
+    from face_crop_plus_amd.cropper import landmarks_target
+    g = torch.Generator().manual_seed(2)
+    f = 150
+    tgt = torch.from_numpy(landmarks_target((128, 128), 0.65)).to(device)
+    lm = (tgt.cpu()[None] * 1.5 + 40 + torch.rand(f, 5, 2, generator=g) * 30).to(device)
+    lm[3] = 7.0                                     # five identical points: degenerate, dropped (cropper.py:529-531)
+    lm[77, 2, 1] = float("nan")
+    mat0, ok0 = align.estimate_transform(lm, tgt)
+    total = torch.full((), 5, dtype=torch.int64, device=device)
+    for live in (0, 1, 64, 100, 150, 400):
+        fc = torch.tensor([9, live], dtype=torch.int32, device=device)[1:]       # a view with a storage offset
+        before = int(total.item())
+        mat, ok = align.estimate_transform(lm, tgt, False, fc, total)
+        torch.cuda.synchronize()
+        k = min(live, f)
+        assert torch.equal(mat[:k], mat0[:k]) and torch.equal(ok[:k], ok0[:k])
+        assert int(ok[k:].sum()) == 0 and float(mat[k:].abs().sum()) == 0.0
+        assert int(total.item()) - before == int(ok0[:k].sum())
+    assert int(ok0.sum()) == f - 2

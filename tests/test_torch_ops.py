@@ -68,3 +68,33 @@ def test_tail_ops_equal_ctypes(device):
     assert torch.equal(l2, labels) and torch.equal(c2, counts)
     with pytest.raises(RuntimeError, match="dtype"):
         ops.bicubic_down4_round(x4.double())
+
+
+@pytest.mark.gpu
+def test_ops_reject_bad_shapes_and_declare_aliasing(device):
+    """Misuse gives RuntimeError (TORCH_CHECK), not an out-of-bounds device read; the in-place variant of the conv op
+    declares its write, the allocating one returns a fresh tensor."""
+    from face_crop_plus_amd import torch_ops as T
+    ops = T.load()
+    assert "Tensor(a!) out" in str(torch.ops.fcp.conv2d_out.default._schema)
+    assert "(a!)" not in str(torch.ops.fcp.conv2d.default._schema)
+    h = [torch.zeros(2, -(-96 // s), -(-128 // s), 32, device=device) for s in (8, 16, 32)]
+    ops.retina_decode(h[0], h[1], h[2], 96, 128, 0.6, 0.1, 0.2)
+    with pytest.raises(RuntimeError, match="head map of stride 16"):
+        ops.retina_decode(h[0], h[2], h[2], 96, 128, 0.6, 0.1, 0.2)
+    with pytest.raises(RuntimeError, match="head map of stride 8"):
+        ops.retina_decode(h[0], h[1], h[2], 192, 128, 0.6, 0.1, 0.2)           # heads too small for this image size
+    score = torch.zeros(2, 100, device=device)
+    count = torch.zeros(2, dtype=torch.int32, device=device)
+    with pytest.raises(RuntimeError, match="cand_box"):
+        ops.nms_select(score, torch.zeros(2, 50, 4, device=device), count, 0.4, 0)
+    with pytest.raises(RuntimeError, match="cand_count"):
+        ops.nms_select(score, torch.zeros(2, 100, 4, device=device), count[:1], 0.4, 0)
+    sel = torch.zeros(2, 100, dtype=torch.int32, device=device)
+    with pytest.raises(RuntimeError, match="cand_ldm"):
+        ops.gather_faces(torch.zeros(2, 50, 10, device=device), sel, count, None, 4)
+    with pytest.raises(RuntimeError, match="max_faces"):
+        ops.gather_faces(torch.zeros(2, 100, 10, device=device), sel, count, None, 0)
+    with pytest.raises(RuntimeError, match="mat must be"):
+        ops.warp_affine_u8(torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device=device), torch.zeros(2, dtype=torch.int32, device=device),
+                           torch.zeros(1, 2, 3, dtype=torch.float64, device=device), None, None, 4, 4, 0)
