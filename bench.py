@@ -274,8 +274,12 @@ def conv_roofline(p: Pipeline, nsteps, live, timed_ms=None, traffic_key=None):
     if not live:
         saved, p.det.streams = p.det.streams, 1
         graphed, p.graphed = p.graphed, None          # per-launch events need the eager launches
-        p.step(False)                                  # shapes first seen on one stream (untimed)
+        # the full-batch shapes of the single-stream pass are new to the tile tuner (the timed region tuned the
+        # sub-batch shapes of its streams): tune them in an untimed step, like the timed region's initialisation pass
+        tuned, E.Autotune.enabled = E.Autotune.enabled, True
+        p.step(False)
         torch.cuda.synchronize()
+        E.Autotune.enabled = tuned
         E.ConvStats.timing = []
         for _ in range(nsteps):
             p.step(False)

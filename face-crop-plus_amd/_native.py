@@ -33,11 +33,12 @@ class ConvDesc(C.Structure):
         ("res1_w", C.c_int32), ("res2_ld", C.c_int32), ("precision", C.c_int32),
         ("in_fmt", C.c_int32), ("out_fmt", C.c_int32), ("res1_fmt", C.c_int32), ("res2_fmt", C.c_int32),
         ("tile_m", C.c_int32), ("cin2", C.c_int32), ("in2_ld", C.c_int32), ("in2_h", C.c_int32),
-        ("in2_w", C.c_int32), ("in2_stride", C.c_int32), ("flags", C.c_int32),
+        ("in2_w", C.c_int32), ("in2_stride", C.c_int32), ("flags", C.c_int32), ("cu_budget", C.c_int32),
     ]
 
 
-CONV_FLAT_ADDR = 1   # fcp_conv_desc.flags: FCP_CONV_FLAT_ADDR
+CONV_FLAT_ADDR = 1      # fcp_conv_desc.flags: FCP_CONV_FLAT_ADDR
+CONV_BALANCE_TAIL = 2   # fcp_conv_desc.flags: FCP_CONV_BALANCE_TAIL
 
 
 class ChainDesc(C.Structure):

@@ -348,6 +348,9 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
 #endif
   static const int nt_env = getenv("FCP_NT_STORE") ? atoi(getenv("FCP_NT_STORE")) : 1;
   k.nt_store = nt_env;
+  k.balance = (d->flags & FCP_CONV_BALANCE_TAIL) ? 1 : 0;
+  k.cu_budget = d->cu_budget;
+  k.mfull = 0; k.tail_rows = 0; k.round_size = 0;
   k.in2 = nullptr; k.in2_bytes = 0; k.csplit = d->cin; k.in2_ld = 0; k.ph2 = 0; k.pw2 = 0; k.stride2 = 1;
   if (d->in2) {
     FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && !d->in_up2 && d->kh == 1 && d->kw == 1 && d->pad == 0,

@@ -15,6 +15,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FCP_ABLATE(p, bits) 0
 #endif
 
+// Cache policy of the LDS-DMA operand loads (the `aux` immediate of raw.ptr.buffer.load.lds on gfx950: 1 = sc0,
+// 2 = nt, 16 = sc1): activations (A) and filters (B) separately; experiment builds override them.
+#ifndef FCP_AUX_A
+#define FCP_AUX_A 0
+#endif
+#ifndef FCP_AUX_B
+#define FCP_AUX_B 0
+#endif
+
 namespace fcp_conv {
 
 constexpr int BM = 128;   // output pixels per workgroup tile
@@ -43,6 +52,10 @@ struct ConvK {
   unsigned in2_bytes;
   int csplit, in2_ld, ph2, pw2, stride2;
   int nt_store;   // 1: split32 outputs are written with non-temporal (streaming) stores
+  // 256-row kernel only: M-tile schedule (see conv_igemm_f16x3_big).  `balance` / `cu_budget` come from the descriptor,
+  // the launcher derives the rest.
+  int balance, cu_budget;
+  int mfull, tail_rows, round_size;
 };
 
 

@@ -60,14 +60,14 @@ struct ResRows {
 
 // passes [g0, g0 + NP) of the half tile
 template <int NP>
-__device__ __forceinline__ void load_res1_rows(const ConvK& p, int tile_m, int co_base, int tid, int hw, int g0, ResRows<NP>& r) {
+__device__ __forceinline__ void load_res1_rows(const ConvK& p, int m_start, int m_end, int co_base, int tid, int hw, int g0, ResRows<NP>& r) {
   int co = co_base + (tid % E_CPR) * 8;
   co = co < p.cout ? co : 0;                                     // inactive lanes read a valid dummy
-  const long m0 = (long)tile_m * BMB + tid / E_CPR;
+  const long m0 = (long)m_start + tid / E_CPR;
 #pragma unroll
   for (int g = 0; g < NP; ++g) {
     long m = m0 + (long)(g0 + g) * E_RPP;
-    m = m < p.M ? m : (long)p.M - 1;
+    m = m < m_end ? m : (long)m_end - 1;
     long rpix = m;
     if (p.res1_resize) {
       const int ni = (int)(m / hw);
@@ -88,13 +88,13 @@ __device__ __forceinline__ void load_res1_rows(const ConvK& p, int tile_m, int c
 }
 
 template <int NP>
-__device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, int tile_m, int co_base, int tid, int hw,
+__device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, int m_start, int m_end, int co_base, int tid, int hw,
                                               int g0, const ResRows<NP>& res) {
   const int ccol = (tid % E_CPR) * 8;
   const int crow = tid / E_CPR;
   const int co = co_base + ccol;
   if (co >= p.cout) return;
-  const long m0 = (long)tile_m * BMB + crow;
+  const long m0 = (long)m_start + crow;
   float bias8[8], ws8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, i
         r1[0] = fa[0]; r1[1] = fa[1]; r1[2] = fa[2]; r1[3] = fa[3]; r1[4] = fb[0]; r1[5] = fb[1]; r1[6] = fb[2]; r1[7] = fb[3];
       }
     }
-    if (p.res2 != nullptr && m < p.M) load8(p.res2, m, p.res2_ld, co, p.res2_fmt, r2);
+    if (p.res2 != nullptr && m < m_end) load8(p.res2, m, p.res2_ld, co, p.res2_fmt, r2);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float x = v[e] * ws8[e] + bias8[e];
@@ -130,7 +130,7 @@ __device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, i
       if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
       v[e] = x;
     }
-    if (m >= p.M) continue;
+    if (m >= m_end) continue;
     if (p.out_fmt == 1) {
       u32x4_t hi, lo;
       split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
@@ -146,13 +146,13 @@ __device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, i
 }
 
 // Row-at-a-time variant (no extra registers): used by the 256-column tile, whose main loop has none to spare.
-__device__ __forceinline__ void epilogue_rows_seq(const ConvK& p, const float* Cs, int tile_m, int co_base, int tid, int hw) {
+__device__ __forceinline__ void epilogue_rows_seq(const ConvK& p, const float* Cs, int m_start, int m_end, int co_base, int tid, int hw) {
   constexpr int CPR = 128 / 8, RPP = NT / CPR, PASSES = BMB / RPP;
   const int ccol = (tid % CPR) * 8;
   const int crow = tid / CPR;
   const int co = co_base + ccol;
   if (co >= p.cout) return;
-  const long m0 = (long)tile_m * BMB + crow;
+  const long m0 = (long)m_start + crow;
   float bias8[8], ws8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -163,7 +163,7 @@ __device__ __forceinline__ void epilogue_rows_seq(const ConvK& p, const float* C
   for (int g = 0; g < PASSES; ++g) {
     const int row = crow + g * RPP;
     const long m = m0 + (long)g * RPP;
-    if (m >= p.M) continue;
+    if (m >= m_end) break;                       // rows ascend with g: nothing further belongs to this tile
     float v[8], r1[8], r2[8];
     {
       const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * 128 + ccol);
@@ -221,12 +221,23 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
 
+  // Workgroup -> tile.  The grid is consumed in dispatch rounds of `round_size` workgroups (one per CU the launch may
+  // count on); inside a round every XCD (workgroup id mod 8) owns a contiguous run of tiles.  Tile order = M-tile major,
+  // and the M-tiles are `mfull` tiles of 256 rows followed by tiles of `tail_rows` rows: the last, partial round is
+  // made of shorter tiles that together fill all CUs instead of full-height tiles on a fraction of them.  Splitting M
+  // never changes a result: every output pixel still sees the same K loop.
   const int nb = gridDim.x;
   const int bid = blockIdx.x;
-  const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int rbase = (bid / p.round_size) * p.round_size;
+  const int nr = nb - rbase < p.round_size ? nb - rbase : p.round_size;
+  const int bi = bid - rbase;
+  const int q8 = nr >> 3, r8 = nr & 7, xcd = bi & 7;
+  const int logical = rbase + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bi >> 3);
   const int tile_n = logical % p.grid_n;
   const int tile_m = logical / p.grid_n;
+  const int m_start = tile_m < p.mfull ? tile_m * BMB : p.mfull * BMB + (tile_m - p.mfull) * p.tail_rows;
+  const int m_rows = tile_m < p.mfull ? BMB : p.tail_rows;
+  const int m_end = m_start + m_rows < p.M ? m_start + m_rows : p.M;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -240,11 +251,11 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   unsigned base2[A_LD];   // second source of a 1x1 conv (channels >= csplit), or unused
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
-    const int m = tile_m * BMB + lrow + 64 * i;
+    const int m = m_start + lrow + 64 * i;
     unsigned pbase = 0;
     int hi0 = -(1 << 28), wi0 = 0;
     base2[i] = 0xFFFFFFFFu;
-    if (m < p.M) {
+    if (m < m_end) {
       const int ni = m / hw;
       const int rem = m - ni * hw;
       const int ho = rem / p.out_w;
@@ -292,7 +303,7 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
       for (int i = 0; i < A_LD; ++i) {
         const unsigned ro = base2[i];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, (__attribute__((address_space(3))) void*)(a + 64 * i * ROWB), 16,
-                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)((c0 - p.csplit) * 4)), 0, 0, 0);
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)((c0 - p.csplit) * 4)), 0, 0, FCP_AUX_A);
       }
     } else {
 #pragma unroll
@@ -303,16 +314,16 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
         const unsigned ro = rowoff[i];
 #endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 64 * i * ROWB), 16,
-                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, 0);
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, FCP_AUX_A);
       }
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 64 * i * ROWB), 16,
 #if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 8)      // filter DMA out of range
-                                               (int)(kt >= 2 ? 0xFFFFFFFFu : woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
+                                               (int)(kt >= 2 ? 0xFFFFFFFFu : woff[i] + (unsigned)(kt * BK * 4)), 0, 0, FCP_AUX_B);
 #else
-                                               (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
+                                               (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, FCP_AUX_B);
 #endif
   };
 
@@ -338,10 +349,30 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     bH[s] = brow + oh; bL[s] = brow + ol;
   }
 
-  f16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];   // [fragment set]
+  // prologue: slices 0 and 1 in flight, slice 0 landed, its first k-half in F0
+  set_tap(0, 0, 0);
+  dma_slice(0, 0);
+  if (p.ktiles > 1) {
+    advance();
+    dma_slice(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  // Rows of this tile the wave owns, in MFMA sub-tiles of 32: TM for a full tile, fewer (down to 0) in a tail tile.  The
+  // main loop is instantiated per count (wave-uniform dispatch): a wave with fewer sub-tiles issues fewer MFMAs and
+  // fragment reads but the same DMA share and the same barriers, so the two waves of a SIMD (w, w + 4: with the 256-column
+  // tile they are the two row halves) split the matrix pipe of that SIMD in proportion to the rows that exist.
+  int tm_act = (m_end - m_start - wm * WTM + 31) >> 5;
+  tm_act = __builtin_amdgcn_readfirstlane(tm_act < 0 ? 0 : (tm_act > TM ? TM : tm_act));
+  auto main_loop = [&](auto tma_c) {
+    constexpr int TMA = decltype(tma_c)::value;
+    f16x8 fah[2][TMA > 0 ? TMA : 1], fal[2][TMA > 0 ? TMA : 1], fbh[2][TN], fbl[2][TN];   // [fragment set]
   auto read_frags = [&](auto set_c, unsigned stage_xor) {   // set s holds k-half s
     constexpr int set = decltype(set_c)::value;
-    static_for<0, TM>([&](auto ic) {
+    static_for<0, TMA>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       fah[set][i] = lds_read128<i * 32 * ROWB>(aH[set] ^ stage_xor);
       fal[set][i] = lds_read128<i * 32 * ROWB>(aL[set] ^ stage_xor);
@@ -355,15 +386,15 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   constexpr std::integral_constant<int, 0> SET0{};
   constexpr std::integral_constant<int, 1> SET1{};
   // MFMAs on fragment set CS with the reads of set LS (from the stage at `stage_xor`) between them, one read per
-  // TM * TN * 3 / (2 TM + 2 TN) MFMAs: the LDS requests of the eight lockstep waves arrive spread over the phase
-  // instead of as one burst of 8 x (2 TM + 2 TN) in front of it.  (Reads past the last slice fetch stale LDS
+  // TMA * TN * 3 / (2 TMA + 2 TN) MFMAs: the LDS requests of the eight lockstep waves arrive spread over the phase
+  // instead of as one burst of 8 x (2 TMA + 2 TN) in front of it.  (Reads past the last slice fetch stale LDS
   // contents nobody consumes: cheaper than a branch.)
   auto mfmas_reads = [&](auto cs_c, auto ls_c, unsigned stage_xor) {
     constexpr int cs = decltype(cs_c)::value, ls = decltype(ls_c)::value;
-    constexpr int NM = 3 * TM * TN, NR = 2 * TM + 2 * TN;
+    constexpr int NM = 3 * TMA * TN, NR = 2 * TMA + 2 * TN;
     static_for<0, NM>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      constexpr int g = m / (TM * TN), i = (m % (TM * TN)) / TN, j = m % TN;
+      constexpr int g = m / (TMA * TN), i = (m % (TMA * TN)) / TN, j = m % TN;
 #if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 2)
       asm volatile("" : "+v"(acc[i][j]) : "v"(fal[cs][i]), "v"(fah[cs][i]), "v"(fbh[cs][j]), "v"(fbl[cs][j]));
 #else
@@ -380,12 +411,12 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
                       && false
 #endif
         ) {
-          if constexpr (r < 2 * TM) {
+          if constexpr (r < 2 * TMA) {
             constexpr int ii = r / 2;
             if constexpr (r % 2 == 0) fah[ls][ii] = lds_read128<ii * 32 * ROWB>(aH[ls] ^ stage_xor);
             else fal[ls][ii] = lds_read128<ii * 32 * ROWB>(aL[ls] ^ stage_xor);
           } else {
-            constexpr int jj = (r - 2 * TM) / 2;
+            constexpr int jj = (r - 2 * TMA) / 2;
             if constexpr (r % 2 == 0) fbh[ls][jj] = lds_read128<jj * 32 * ROWB>(bH[ls] ^ stage_xor);
             else fbl[ls][jj] = lds_read128<jj * 32 * ROWB>(bL[ls] ^ stage_xor);
           }
@@ -395,18 +426,6 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     });
   };
 
-  // prologue: slices 0 and 1 in flight, slice 0 landed, its first k-half in F0
-  set_tap(0, 0, 0);
-  dma_slice(0, 0);
-  if (p.ktiles > 1) {
-    advance();
-    dma_slice(1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
   read_frags(SET0, 0u);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -433,7 +452,9 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     //      64 requests: with all eight waves issuing their A_LD + B_LD instructions at once (64 KiB per slice through a
     //      64 B/clk path) cycle probes showed BOTH waves of a SIMD stuck there for 800-1700 cycles per slice with the
     //      matrix pipe idle.  The two waves of a SIMD (w, w+4) therefore take the two jobs in opposite order: one
-    //      feeds the matrix pipe while the other sits in the queue.
+    //      feeds the matrix pipe while the other sits in the queue.  (Round 3, negative: the same instructions issued
+    //      one at a time BETWEEN the MFMAs, spread over the whole window in which the stage is free, are 8-12 % slower —
+    //      every one of them stalls its wave's MFMA stream; profiles/r03_probes.md.)
     const bool dma_first = wave_u >= 4;
     if (dma_first && kt + 2 < p.ktiles) {
       advance();
@@ -458,6 +479,10 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     printf("wave %d: %d slices; k-half 0 (reads+mfma) %llu, wait+barrier %llu, reads+dma issue %llu, k-half 1 mfma %llu\n", wave_u, p.ktiles,
            pc[0], pc[1], pc[2], pc[3]);
 #endif
+  };
+  static_for<0, TM + 1>([&](auto tc) {
+    if (tm_act == decltype(tc)::value) main_loop(tc);
+  });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -469,11 +494,12 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     // The 256-column tile has no registers to spare (254 live in its main loop; any more and the allocator spills
     // there), so it keeps the row-at-a-time epilogue: it is the kernel of the residual-free layers.
     ResRows<E_PASSES> res;
-    if (BN == 128 && p.res1 != nullptr) load_res1_rows<E_PASSES>(p, tile_m, tile_n * BN + h * 128, tid, hw, 0, res);
+    if (BN == 128 && p.res1 != nullptr) load_res1_rows<E_PASSES>(p, m_start, m_end, tile_n * BN + h * 128, tid, hw, 0, res);
     if ((wn * WTN) / 128 == h) {
       const int cbase = wn * WTN - h * 128;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
+        if (i < tm_act)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -484,19 +510,47 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     }
     __syncthreads();
     if constexpr (BN == 128)
-      epilogue_rows<E_PASSES>(p, Cs, tile_m, tile_n * BN + h * 128, tid, hw, 0, res);
+      epilogue_rows<E_PASSES>(p, Cs, m_start, m_end, tile_n * BN + h * 128, tid, hw, 0, res);
     else
-      epilogue_rows_seq(p, Cs, tile_m, tile_n * BN + h * 128, tid, hw);
+      epilogue_rows_seq(p, Cs, m_start, m_end, tile_n * BN + h * 128, tid, hw);
     __syncthreads();
   }
 }
 
+// M-tile schedule.  Uniform: ceil(M / 256) tiles of 256 rows.  Balanced (descriptor flag FCP_CONV_BALANCE_TAIL): the
+// tiles of all FULL dispatch rounds (`cus` workgroups each, one per CU) stay 256 rows high; the rows that are left are cut
+// into tiles of R rows (a multiple of 32, <= 256) so that the last round has a tile for (nearly) every CU:
+//   e.g. M = 102400, one N-tile, 256 CUs: 400 uniform tiles = 2 rounds (the second on 144 CUs);
+//        balanced: 256 tiles of 256 rows + 231 tiles of 160 rows = 1 + ~0.7 rounds.
+// A launch with less than one round of uniform tiles is all "tail".  Results do not depend on the schedule.
 template <int BN>
 int launch(ConvK k, hipStream_t s) {
   const size_t lds = 2 * (size_t)STAGE;   // two stages; the epilogue's 256 x 128 fp32 tile aliases them
   FCP_LDS_OPT_IN((&conv_igemm_f16x3_big<BN>), lds);
-  k.grid_m = fcp_cdiv(k.M, BMB);
   k.grid_n = fcp_cdiv(k.cout, BN);
+  int cus = k.cu_budget > 0 ? k.cu_budget : fcp_cu_count();
+  cus = cus < 8 ? 8 : (cus & ~7);                                    // rounds are XCD-interleaved: a multiple of 8
+  k.round_size = cus;
+  const int mt = fcp_cdiv(k.M, BMB);
+  k.mfull = mt;
+  k.tail_rows = BMB;
+  k.grid_m = mt;
+  if (k.balance) {
+    const long tiles = (long)mt * k.grid_n;
+    const long full_rounds = tiles / cus;
+    const int mfull = (int)((full_rounds * cus) / k.grid_n);         // whole M-tiles inside the full rounds
+    const long rem = (long)k.M - (long)mfull * BMB;
+    if (rem > 0) {
+      const long slots = cus / k.grid_n > 0 ? cus / k.grid_n : 1;     // M-tiles one round has room for
+      long r = ((rem + slots - 1) / slots + 31) / 32 * 32;
+      r = r < 32 ? 32 : r;
+      if (r < BMB) {
+        k.mfull = mfull;
+        k.tail_rows = (int)r;
+        k.grid_m = mfull + (int)((rem + r - 1) / r);
+      }
+    }
+  }
   hipLaunchKernelGGL((conv_igemm_f16x3_big<BN>), dim3(k.grid_m * k.grid_n), dim3(NT), lds, s, k);
   FCP_LAUNCH_OK();
   return 0;

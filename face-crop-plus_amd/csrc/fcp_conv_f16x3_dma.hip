@@ -129,20 +129,20 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : 3)) conv_igemm_f16x3_dma
       for (int i = 0; i < A_LD; ++i) {
         const unsigned ro = base2[i];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, (__attribute__((address_space(3))) void*)(a + 32 * i * ROWB), 16,
-                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)((c0 - p.csplit) * 4)), 0, 0, 0);
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)((c0 - p.csplit) * 4)), 0, 0, FCP_AUX_A);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         const unsigned ro = rowoff[i];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * i * ROWB), 16,
-                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, 0);
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, FCP_AUX_A);
       }
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 32 * i * ROWB), 16,
-                                               (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
+                                               (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, FCP_AUX_B);
   };
 
   // residual tile first: its HBM round trip overlaps the whole main loop

@@ -195,6 +195,21 @@ def _pick_tile_n(cout: int, m: int) -> int:
 
 
 BIG_TILES = os.environ.get("FCP_BIG_TILES", "1") != "0"   # offer the 256-row kernel to the autotuner
+BALANCE_TAIL = os.environ.get("FCP_BALANCE_TAIL", "1") != "0"   # and its balanced M-tile schedule (FCP_CONV_BALANCE_TAIL)
+
+_budget = threading.local()
+
+
+@contextlib.contextmanager
+def cu_budget(cus: int):
+    """CUs the 256-row conv launches of this thread may count on when they lay out their last dispatch round (0 = the
+    whole device).  A caller that runs k sub-batches concurrently on k streams passes 1/k of the device."""
+    prev = getattr(_budget, "cus", 0)
+    _budget.cus = int(cus)
+    try:
+        yield
+    finally:
+        _budget.cus = prev
 
 
 class Autotune:
@@ -255,12 +270,13 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
          alpha: float = 1.0, res1: Act | None = None, res1_pre: bool = True,
          res2: Act | None = None, alpha2: float = 1.0, in_up2: bool = False,
          tile_n: int | None = None, out_fmt: int = 0, tile_m: int | None = None,
-         x2: Act | None = None, x2_stride: int = 1, flat: bool = False) -> Act:
+         x2: Act | None = None, x2_stride: int = 1, flat: bool = False, balance_tail: bool = False) -> Act:
     """Launch one fused convolution.  ``act_slope``: 1 = identity, 0 = ReLU.  ``out_fmt`` selects the
     format of a freshly allocated output (an explicit ``out`` view carries its own).  ``x2``: second
     source of a 1x1 conv — the filter's trailing ``x2.c`` input channels read ``x2`` at
     ``(ho*x2_stride, wo*x2_stride)`` (both sources split32, fp16x3 path).  ``flat``: force the 64-bit
-    flat-addressing variant of the fp32 kernel (what tensors >= 4 GiB take on their own)."""
+    flat-addressing variant of the fp32 kernel (what tensors >= 4 GiB take on their own).  ``balance_tail`` (with an
+    explicit ``tile_m=256``): the balanced M-tile schedule of the 256-row kernel (the autotuner picks it by itself)."""
     assert x.c + (x2.c if x2 is not None else 0) == pc.cin, f"conv expects {pc.cin} input channels, got {x.c}"
     in_h, in_w = (x.h * 2, x.w * 2) if in_up2 else (x.h, x.w)
     oh = (in_h + 2 * pc.pad - pc.kh) // pc.stride + 1
@@ -293,7 +309,8 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     d.cin4 = int(pc.cin4)
     d.act_slope, d.alpha, d.alpha2 = act_slope, alpha, alpha2
     d.res1_pre = int(res1_pre)
-    d.flags = N.CONV_FLAT_ADDR if flat else 0
+    d.flags = (N.CONV_FLAT_ADDR if flat else 0) | (N.CONV_BALANCE_TAIL if balance_tail else 0)
+    d.cu_budget = getattr(_budget, "cus", 0)
     if res1 is not None:
         assert res1.c == pc.cout and res1.n == x.n
         d.res1_ld, d.res1_h, d.res1_w = res1.ld, res1.h, res1.w
@@ -306,7 +323,7 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
                and pc.cout <= 64 and pc.cout % 8 == 0 and pc.cin >= 64 and x2 is None and (res1 is None or (res1.h, res1.w) == (oh, ow)))
     if tile_n is None and tile_m is None and (pc.cout > 64 or halo_ok) and (Autotune.enabled or Autotune.cache):
         key = (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, m, int(in_up2), res1 is not None, res2 is not None,
-               pc.precision, x.fmt, out.fmt, None if x2 is None else (x2.c, x2_stride))
+               pc.precision, x.fmt, out.fmt, None if x2 is None else (x2.c, x2_stride), d.cu_budget)
         best = Autotune.cache.get(key)          # a tuned shape keeps its tile after tuning is switched off
         if best is None and Autotune.enabled:
             # Tuning launches the op several times.  An op whose output aliases one of its inputs (RRDB's last dense-block
@@ -320,8 +337,11 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
             aliased = any(same(t) and t.c0 < out.c0 + out.c and out.c0 < t.c0 + t.c for t in (x, x2, res1, res2))
             scratch = torch.empty((out.n, out.h, out.w, out.c), dtype=torch.float32, device=out.buf.device) if aliased else None
 
+            base_flags = d.flags
+
             def _launch(t):
-                d.tile_m, d.tile_n = t
+                d.tile_m, d.tile_n = t[0], t[1]
+                d.flags = base_flags | (t[2] if len(t) > 2 else 0)
                 if scratch is not None:
                     d.out, d.out_ld = N.ptr(scratch), out.c
                 N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
@@ -330,10 +350,15 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
             if halo_ok:
                 cands = ([(128, 32)] if pc.cout <= 32 else []) + [(128, 64), (1, 32)]
             if big_ok and BIG_TILES:
-                cands += [(256, 128)] + ([(256, 256)] if pc.cout >= 256 else [])
+                big = [(256, 128)] + ([(256, 256)] if pc.cout >= 256 else [])
+                cands += big
+                if BALANCE_TAIL:      # the same tiles with the last dispatch round cut into shorter M-tiles (same bits)
+                    cands += [(tm, tn, N.CONV_BALANCE_TAIL) for tm, tn in big]
             best = Autotune.pick(key, cands, _launch)
+            d.flags = base_flags
         if best is not None:
-            d.tile_m, d.tile_n = best
+            d.tile_m, d.tile_n = best[0], best[1]
+            d.flags |= best[2] if len(best) > 2 else 0
     timing = ConvStats.timing
     if timing is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -345,7 +370,7 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
                             out.buf, out.c0, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, float(act_slope), float(alpha), float(alpha2),
                             bool(res1_pre), pc.precision, x.fmt, out.fmt, d.res1_fmt, d.res2_fmt, bool(in_up2), bool(pc.cin4),
                             int(d.tile_m), int(d.tile_n), None if x2 is None else x2.buf, 0 if x2 is None else x2.c0,
-                            0 if x2 is None else x2.c, int(x2_stride), int(d.flags))
+                            0 if x2 is None else x2.c, int(x2_stride), int(d.flags), int(d.cu_budget))
     else:
         N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
     if timing is not None:

@@ -46,6 +46,7 @@ class RetinaFace:
         self.fused_chain = os.environ.get("FCP_FUSED_CHAIN", "1") != "0"
         self.streams = int(os.environ.get("FCP_DET_STREAMS", "2"))
         self.min_images_per_stream = 8
+        self.split_cu_budget = os.environ.get("FCP_SPLIT_CU_BUDGET", "1") != "0"
         self._tls = threading.local()
 
     # ------------------------------------------------------------------ load
@@ -213,10 +214,12 @@ class RetinaFace:
         cur = torch.cuda.current_stream(dev)
         bounds = [n * i // k for i in range(k + 1)]
         side = self._side_streams(dev, k)
+        # each sub-batch lays out the last dispatch round of its 256-row conv launches for its share of the CUs
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count // k if self.split_cu_budget else 0
         for st, a, b in zip(side, bounds[:-1], bounds[1:]):
             tuned = len(E.Autotune.cache)
             st.wait_stream(cur)
-            with torch.cuda.stream(st):
+            with torch.cuda.stream(st), E.cu_budget(cus):
                 self.forward_heads(None, images_u8[a:b], [E.Act(hd.buf[a:b]) for hd in heads])
             if len(E.Autotune.cache) != tuned:
                 # this sub-batch met untuned shapes (first call of a geometry): their tile candidates were timed with HIP

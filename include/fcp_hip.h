@@ -111,9 +111,15 @@ typedef struct fcp_conv_desc {
    * 4 GiB.  The flat path is what tensors >= 4 GiB take on their own (RRDB's x4-resolution tail at 1024^2
    * inputs); the flag exists so that it can be exercised — and tested — at small sizes. */
   int32_t flags;
+  /* FCP_CONV_BALANCE_TAIL (256-row tiles, tile_m = 256): cut the rows of the last, partial dispatch round into
+   * shorter M-tiles that together occupy every CU (instead of 256-row tiles on a fraction of them).  `cu_budget` =
+   * CUs the launch may count on (0 = all of the device; a caller that runs two such launches concurrently on two
+   * streams passes half).  Neither changes a result. */
+  int32_t cu_budget;
 } fcp_conv_desc;
 
 #define FCP_CONV_FLAT_ADDR 1
+#define FCP_CONV_BALANCE_TAIL 2
 
 int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);
 

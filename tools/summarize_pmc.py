@@ -9,7 +9,12 @@ on gfx950 FETCH_SIZE counts 128-byte requests as 64 B for wide coalesced reads, 
 import collections, csv, json, sys
 
 src, dst = sys.argv[1], sys.argv[2]
-LAUNCHES = int(sys.argv[3]) if len(sys.argv) > 3 else 66     # conv launches of one detection step
+LAUNCHES = int(sys.argv[3]) if len(sys.argv) > 3 else 66     # conv launches of one step
+# optional: images per step and side of the detector input (calibration launch = layer1.0.conv1 reading the pooled stem
+# map n x (side/4)^2 x 64 x 4 B once) and a description of the command
+CAL_N = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+CAL_SIDE = int(sys.argv[5]) if len(sys.argv) > 5 else 640
+WHAT = sys.argv[6] if len(sys.argv) > 6 else "bench.py --steps 1 --warmup 1 --no-cpu-baseline (batch 64, 640x640)"
 
 
 def load(path):
@@ -28,12 +33,12 @@ write_kib = sum(v["WRITE_SIZE"] for v in w)
 # launch, layer1.0.conv1, reads the pooled 64-channel stem map (64 x 160 x 160 x 64 x 4 B) once.
 fused = "stem_pool_kernel" in f[0]["name"]
 cal = 1 if fused else 0
-stem_expected_kib = (64 * 160 * 160 * 64 * 4 if fused else 64 * 640 * 640 * 16) / 1024
+stem_expected_kib = (CAL_N * (CAL_SIDE // 4) ** 2 * 64 * 4 if fused else CAL_N * CAL_SIDE * CAL_SIDE * 16) / 1024
 read_corr = 2.0
 mfma_busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in s)
 gui = sum(v["GRBM_GUI_ACTIVE"] for v in s)               # summed over the 8 XCDs
 out = {
-    "command": f"bench.py --steps 1 --warmup 1 --no-cpu-baseline (batch 64, 640x640), last step's {LAUNCHES} conv launches",
+    "command": f"{WHAT}, last step's {LAUNCHES} conv launches",
     "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
     "fetch_calibration": {"launch": f[cal]["name"][:60], "reported_kib": f[cal]["FETCH_SIZE"],
                           "expected_kib": stem_expected_kib, "ratio": f[cal]["FETCH_SIZE"] / stem_expected_kib,
