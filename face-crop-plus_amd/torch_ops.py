@@ -4,10 +4,13 @@
 ``csrc/libfcp_torch.so`` (built by ``build_native.py`` from ``csrc/torch_ops/fcp_torch_ops.cpp``) registers the ops with
 ``TORCH_LIBRARY(fcp, ...)`` / ``TORCH_LIBRARY_IMPL(fcp, CUDA, ...)``: tensors in / out, outputs from torch's caching
 allocator, work enqueued on the current HIP stream, misuse -> ``RuntimeError`` via ``TORCH_CHECK``.  They are a veneer
-over the C ABI of ``include/fcp_hip.h`` (same kernels, same bits).  The host code calls the C ABI through ctypes by
-default (lower per-call overhead: ~70 launches per detection step); ``FCP_BOUNDARY=torch`` routes the convolution engine,
-the detector's post-processing and align / crop through the registered ops instead — both paths are tested to give
-identical tensors.
+over the C ABI of ``include/fcp_hip.h`` (same kernels, same bits).  They are the DEFAULT boundary of the Python host:
+the convolution engine, the detector's post-processing and align / crop go through the registered ops whenever
+``libfcp_torch.so`` has been built (measured on the MI355X, INTEGRATION.md section 2b: 1.8-1.9 ms of host time per batch-64
+detection step through the dispatcher against 1.9-2.0 ms through ctypes, identical step time).  ``FCP_BOUNDARY=ctypes``
+calls the C ABI directly instead (also what happens, with a warning, when the veneer was not built — it is the same
+kernels either way, never a CPU path); ``FCP_BOUNDARY=torch`` insists on the ops and raises when the library is missing.
+Both paths are tested to give identical tensors (``tests/test_torch_ops.py``).
 """
 from __future__ import annotations
 
@@ -18,7 +21,22 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_torch.so")
 _loaded = False
-ENABLED = os.environ.get("FCP_BOUNDARY", "ctypes") == "torch"
+
+
+def _default_enabled() -> bool:
+    mode = os.environ.get("FCP_BOUNDARY", "auto").lower()
+    if mode == "ctypes":
+        return False
+    if mode == "torch":
+        return True
+    if os.path.isfile(LIB_PATH):
+        return True
+    import warnings
+    warnings.warn(f"{LIB_PATH} is missing (the torch.ops.fcp veneer was not built): calling the C ABI through ctypes")
+    return False
+
+
+ENABLED = _default_enabled()
 
 
 def load():

@@ -21,8 +21,8 @@ def test_ops_are_registered_with_a_gpu_kernel():
 
 @pytest.mark.gpu
 def test_detector_and_align_through_ops_equal_ctypes_path(device):
-    """FCP_BOUNDARY=torch routes every conv launch, the fused bottleneck chain, decode / NMS / gather and
-    estimate + warp through the registered ops: all outputs must equal the ctypes path bit for bit."""
+    """The default boundary (FCP_BOUNDARY=auto | torch) routes every conv launch, the fused bottleneck chain, decode / NMS /
+    gather and estimate + warp through the registered ops: all outputs must equal the ctypes path bit for bit."""
     from face_crop_plus_amd import weights, align, torch_ops as T
     from face_crop_plus_amd.retinaface import RetinaFace
     from face_crop_plus_amd.cropper import landmarks_target
@@ -32,6 +32,7 @@ def test_detector_and_align_through_ops_equal_ctypes_path(device):
     pads = torch.tensor([[0, 0, 0, 0], [3, 2, 0, 0], [0, 0, 4, 1], [0, 0, 0, 0]], dtype=torch.int32)
     tgt = landmarks_target((64, 48), 0.65)
     res = {}
+    prev = T.ENABLED
     for mode in (False, True):
         T.ENABLED = mode
         try:
@@ -41,7 +42,7 @@ def test_detector_and_align_through_ops_equal_ctypes_path(device):
             torch.cuda.synchronize()
             res[mode] = (r, crops, ok, mat, nf)
         finally:
-            T.ENABLED = False
+            T.ENABLED = prev
     (a, ca, oa, ma, na), (b, cb, ob, mb, nb) = res[False], res[True]
     assert na == nb and na > 4
     for k in ("landmarks", "img_idx", "face_offset", "cand_count", "keep_count", "sel_count", "cand_prior"):
