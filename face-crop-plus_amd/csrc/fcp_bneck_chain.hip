@@ -43,6 +43,10 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef FCP_CHAIN_STORE_AUX
+#define FCP_CHAIN_STORE_AUX 2     // cache policy of the `out` stores of the chunk loop (0 default, 2 nt, 16 sc1)
+#endif
+
 struct ChainK {
   const float* t1;  unsigned t1_bytes;  int t1_ld;
   const float* w2;  unsigned w2_bytes;  const float* ws2;  const float* b2;
@@ -53,7 +57,7 @@ struct ChainK {
   float* t1n;       int t1n_ld;
   int n, h, w, M;
   int nt_store;
-  int ablate;   // profiling builds only (FCP_CHAIN_ABLATE): 1 no out stores, 2 no residual loads, 4 no phase-1 loop, 8 no chunk loop
+  int ablate;   // profiling builds only (FCP_CHAIN_ABLATE): 1 no out stores, 2 no residual loads, 4 no phase-1 loop, 8 no chunk loop, 16 half the filter DMAs
 };
 
 constexpr int C = 64;                 // bottleneck width of the variant with phase 1
@@ -197,9 +201,11 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
                                                  (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < B_LD; ++i)
+      for (int i = 0; i < B_LD; ++i) {
+        if (FCP_ABLATE(p, 16) && (i & 1)) continue;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 32 * i * ROWB), 16,
                                                  (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
+      }
     };
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -311,6 +317,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
   auto dma_w3 = [&](int j, int buf) {
 #pragma unroll
     for (int i = 0; i < CS; ++i) {
+      if (FCP_ABLATE(p, 16) && (i & 1)) continue;
       const int g = wave_u * CS + i, sl = g >> 2, r = (g & 3) * 8 + (lane >> 3);
       char* dst = lds + W3B_OFF + buf * W3CH + sl * 4096 + (g & 3) * 8 * ROWB;
       const unsigned src = (unsigned)((j * 32 + r) * (CW * 4) + sl * 128 + (((lane & 7) ^ swz(r)) << 4));
@@ -322,6 +329,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
     char* dst = lds + W1B_OFF + buf * (CN * ROWB) + wave_u * (CN / 4) * ROWB;
 #pragma unroll
     for (int i = 0; i < CN / 32; ++i) {
+      if (FCP_ABLATE(p, 16) && (i & 1)) continue;
       const int r = wave_u * (CN / 4) + 8 * i + (lane >> 3);
       const unsigned src = (unsigned)(r * (NOUT * 4) + j * 128 + (((lane & 7) ^ swz(r)) << 4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + 8 * i * ROWB), 16, (int)src, 0, 0, 0);
@@ -331,6 +339,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
   constexpr int NDMA = CS + CN / 32;
   auto dma_one = [&](auto kc, int j, int buf) {
     constexpr int k = decltype(kc)::value;
+    if (FCP_ABLATE(p, 16) && (k & 1)) return;       // profiling builds: half of the filter DMA instructions (wrong results)
     if constexpr (k < CS) {
       const int g = wave_u * CS + k, sl = g >> 2, r = (g & 3) * 8 + (lane >> 3);
       char* dst = lds + W3B_OFF + buf * W3CH + sl * 4096 + (g & 3) * 8 * ROWB;
@@ -582,8 +591,8 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const unsigned o = so[it] == 0xFFFFFFFFu ? 0xFFFFFFFFu : so[it] + (unsigned)(j * 128);
-          __builtin_amdgcn_raw_buffer_store_b128(ohi[it], rs_out, o, 0, 2);                       // aux 2: nt (streamed once)
-          __builtin_amdgcn_raw_buffer_store_b128(olo[it], rs_out, o == 0xFFFFFFFFu ? o : o + 64u, 0, 2);
+          __builtin_amdgcn_raw_buffer_store_b128(ohi[it], rs_out, o, 0, FCP_CHAIN_STORE_AUX);     // aux 2: nt (streamed once)
+          __builtin_amdgcn_raw_buffer_store_b128(olo[it], rs_out, o == 0xFFFFFFFFu ? o : o + 64u, 0, FCP_CHAIN_STORE_AUX);
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);

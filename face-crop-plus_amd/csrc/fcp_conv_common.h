@@ -212,6 +212,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
 
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+// Mixed-precision FMA (v_fma_mix_f32: every source is an f32 register or one binary16 half of a register, one rounding):
+//   fcp_mix_sum(h, l, HI)  = float(h.half) + float(l.half)      — exactly what v_cvt_f32_f16 x2 + v_add_f32 give (the conversions
+//   fcp_mix_diff(x, h, HI) = x - float(h.half)                    are exact, so there is one rounding either way), in ONE instruction.
+// The epilogues of every fp16x3 kernel decode / encode 8-16 values per lane and chunk with these; as separate converts and
+// adds that was a third of the bottleneck-chain kernel's epilogue instructions.
+template <int HI>
+__device__ __forceinline__ float fcp_mix_sum(unsigned h, unsigned l) {
+  float r;
+  const float one = 1.0f;
+  if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "s"(one), "v"(l));
+  else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "s"(one), "v"(l));
+  return r;
+}
+template <int HI>
+__device__ __forceinline__ float fcp_mix_diff(float x, unsigned h) {
+  float r;
+  const float minus_one = -1.0f;
+  if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "s"(minus_one), "v"(x));
+  else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "s"(minus_one), "v"(x));
+  return r;
+}
 
 // 8 fp32 -> 8 hi + 8 lo binary16 (round-toward-zero packs; lo = x - hi is exact in fp32).  Idempotent on
 // values that already are a hi + lo sum, so elementwise kernels may decode / re-encode freely.
@@ -219,24 +242,33 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4_t
   const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const auto h2 = __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]);
+    const unsigned hu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]));
+#ifdef FCP_NO_FMA_MIX
+    const auto h2 = __builtin_bit_cast(f16x2_t, hu);
     const float r0 = x[2 * q] - (float)h2[0];
     const float r1 = x[2 * q + 1] - (float)h2[1];
-    const auto l2 = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-    hi[q] = __builtin_bit_cast(unsigned, h2);
-    lo[q] = __builtin_bit_cast(unsigned, l2);
+#else
+    const float r0 = fcp_mix_diff<0>(x[2 * q], hu);
+    const float r1 = fcp_mix_diff<1>(x[2 * q + 1], hu);
+#endif
+    hi[q] = hu;
+    lo[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
   }
 }
 // inverse: value = float(hi) + float(lo) (exact)
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void join8(const u32x4_t& hi, const u32x4_t& lo, float (&x)[8]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const unsigned hu = hi[q], lu = lo[q];
+#ifdef FCP_NO_FMA_MIX
     const f16x2_t h = __builtin_bit_cast(f16x2_t, hu);
     const f16x2_t l = __builtin_bit_cast(f16x2_t, lu);
     x[2 * q] = (float)h[0] + (float)l[0];
     x[2 * q + 1] = (float)h[1] + (float)l[1];
+#else
+    x[2 * q] = fcp_mix_sum<0>(hu, lu);
+    x[2 * q + 1] = fcp_mix_sum<1>(hu, lu);
+#endif
   }
 }
 // byte offset of channel c (multiple of 8) inside a split32 pixel: group (c/32)*128 B, hi at (c%32)*2, lo +64

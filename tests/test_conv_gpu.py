@@ -165,6 +165,36 @@ def test_split32_roundtrip_and_maxpool(device):
     assert mp.fmt == 1 and torch.equal(mp.nchw().cpu(), F.max_pool2d(back, 3, 2, 1))
 
 
+def test_split32_bits_vs_numpy(device):
+    """The hi / lo split and its inverse, bit for bit against a numpy restatement (hi = x rounded TOWARD ZERO to binary16,
+    lo = (x - hi) rounded toward zero; value = float(hi) + float(lo)), over normal, subnormal-binary16, tiny and large
+    magnitudes: pins the arithmetic of split8 / join8 (one v_fma_mix_f32 per value) in every kernel epilogue."""
+    from face_crop_plus_amd import engine as E
+    rng = np.random.default_rng(5)
+    mags = np.concatenate([rng.normal(0, 1, 20000), rng.normal(0, 300, 20000), rng.normal(0, 1e-4, 20000), rng.normal(0, 3e-6, 20000),
+                           rng.normal(0, 1e-9, 8000), rng.uniform(-65000, 65000, 8000), [0.0, -0.0, 1.0, -1.0, 65504.0, 2.0 ** -24, 2.0 ** -14]])
+    n = (len(mags) // 64) * 64
+    x = mags[:n].astype(np.float32).reshape(1, 1, n // 64, 64)
+
+    def rtz16(v):
+        h = v.astype(np.float16)
+        over = np.abs(h.astype(np.float32)) > np.abs(v)                 # round-to-nearest went away from zero: step back
+        h[over] = np.nextafter(h[over], np.float16(0))
+        return h
+    hi = rtz16(x)
+    lo = rtz16(x - hi.astype(np.float32))
+    sp = E.f32_to_split32(E.Act(torch.from_numpy(x).to(device)))
+    raw = sp.buf.cpu().numpy().view(np.uint16).reshape(1, 1, n // 64, 2, 2, 32)      # [group of 32 channels][hi | lo][32]
+    # a zero lo part may carry either sign (x - hi = +0 or -0): compare values for zeros, bits otherwise
+    got_hi, got_lo = raw[..., 0, :].reshape(x.shape), raw[..., 1, :].reshape(x.shape)
+    assert np.array_equal(got_hi, hi.view(np.uint16))
+    nz = lo != 0
+    assert np.array_equal(got_lo[nz], lo.view(np.uint16)[nz]) and not got_lo.view(np.float16)[~nz].any()
+    back = E.split32_to_f32(sp).buf.cpu().numpy()
+    assert np.array_equal(back, hi.astype(np.float32) + lo.astype(np.float32))
+    assert np.abs(back - x).max() <= 2.0 ** -21 * np.abs(x).max()
+
+
 @pytest.mark.parametrize("k,stride,cin,cout", [(1, 1, 64, 256), (3, 1, 128, 128), (3, 2, 64, 64), (1, 2, 256, 512)])
 def test_conv_split32_in_out_with_residual(k, stride, cin, cout, device, precision):
     """split32 activations end to end: split input, split residual, split output (fp16x3 path only)."""
