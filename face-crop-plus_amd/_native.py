@@ -45,7 +45,7 @@ class ChainDesc(C.Structure):
     """Mirror of ``fcp_chain_desc``."""
     _fields_ = [(k, C.c_void_p) for k in ("t1", "w2", "ws2", "b2", "w3", "ws3", "b3", "res", "out", "w1n", "ws1n",
                                           "b1n", "t1n")] + \
-               [(k, C.c_int32) for k in ("n", "h", "w", "c", "cn", "t1_ld", "res_ld", "out_ld", "t1n_ld", "nout")]
+               [(k, C.c_int32) for k in ("n", "h", "w", "c", "cn", "t1_ld", "res_ld", "out_ld", "t1n_ld", "nout", "tile_m")]
 
 
 # name -> argtypes; every function returns int (0 = ok)

@@ -60,31 +60,35 @@ struct ChainK {
   int ablate;   // profiling builds only (FCP_CHAIN_ABLATE): 1 no out stores, 2 no residual loads, 4 no phase-1 loop, 8 no chunk loop, 16 half the filter DMAs
 };
 
+// Pixels per workgroup tile: BMT = 128 (4 waves, up to two workgroups per CU; the default) or 256 (8 waves, one workgroup per
+// CU: every filter byte the tile fetches — W2, the conv3 groups, the conv1' slices: 45 % of a 128-pixel tile's vector-memory
+// traffic — serves twice the pixels; an option, not faster: profiles/r03_probes.md).  A wave owns 32 rows either way.
 constexpr int C = 64;                 // bottleneck width of the variant with phase 1
 constexpr int ROWB = 128;             // bytes per LDS operand row: 32 hi + 32 lo binary16
-constexpr int STAGE = (BM + C) * ROWB;          // 24 KiB: one phase-1 stage (A rows then B rows)
-constexpr int CT_OFF = 0;                       // chunk loop: 128 x 32 fp32 epilogue tile, rewritten in place as T3 (16 KiB)
-constexpr int W1B_OFF = 16384;                  // chunk loop: K slice j of conv1' (CN rows x 128 B, <= 16 KiB)
-// conv1' K slices are double-buffered wherever LDS allows (everything but the 80 KiB / CN = 128 variant): the next
-// slice's DMA can then be issued BEFORE the chunk's `out` stores, see the chunk loop
-constexpr bool w1_double(int cn, bool has_c2) { return !(has_c2 && cn == 128); }
-constexpr int w3b_off(int cn, bool has_c2) { return W1B_OFF + (w1_double(cn, has_c2) ? 2 : 1) * cn * 128; }   // conv3 filter groups, 2 x (CW * 128 B)
-// region 0 = phase-1 stages | epilogue tiles | chunk buffers; the operand tile T2 (BM x CW, 4 B per element) follows it
-constexpr int r0_bytes(int cw, int cn, bool has_c2) { return has_c2 ? 2 * STAGE : w3b_off(cn, has_c2) + 2 * cw * 128; }
+constexpr int stage_bytes(int bmt) { return (bmt + C) * ROWB; }       // one phase-1 stage (A rows then B rows): 24 | 40 KiB
+constexpr int CT_OFF = 0;                       // chunk loop: BMT x 32 fp32 epilogue tile, rewritten in place as T3 (16 | 32 KiB)
+constexpr int w1b_off(int bmt) { return bmt * 128; }                  // chunk loop: K slice j of conv1' (CN rows x 128 B)
+// conv1' K slices are double-buffered wherever LDS allows (everything but the 128-pixel conv2 form with CN = 128, whose
+// chunk buffers live in the 48 KiB of the dead phase-1 stages): the next slice's DMA can then be issued BEFORE the chunk's
+// `out` stores, see the chunk loop
+constexpr bool w1_double(int bmt, int cn, bool has_c2) { return !has_c2 || w1b_off(bmt) + 2 * cn * 128 + 2 * C * 128 <= 2 * stage_bytes(bmt); }
+constexpr int w3b_off(int bmt, int cn, bool has_c2) { return w1b_off(bmt) + (w1_double(bmt, cn, has_c2) ? 2 : 1) * cn * 128; }   // conv3 filter groups, 2 x (CW * 128 B)
+// region 0 = phase-1 stages | epilogue tiles | chunk buffers; the operand tile T2 (BMT x CW, 4 B per element) follows it
+constexpr int r0_bytes(int bmt, int cw, int cn, bool has_c2) { return has_c2 ? 2 * stage_bytes(bmt) : w3b_off(bmt, cn, has_c2) + 2 * cw * 128; }
 // In the pair forms T2 ALIASES the chunk buffers: a wave's T2 fragments are the same for every chunk and live in
 // registers, so the tile is only needed until they have been read.  That is what lets the 256-wide pair fit at all
 // (144 + 128 KiB otherwise) and brings the 128-wide pairs down to 80 KiB: TWO workgroups per CU, the second one's
 // MFMAs under the first one's epilogue (FCP_CHAIN_NOALIAS: the 128-wide pairs as before, 128-144 KiB, one per CU).
 #ifdef FCP_CHAIN_NOALIAS
-constexpr bool alias_t2(int cw, int cn, bool has_c2) { return !has_c2 && r0_bytes(cw, cn, has_c2) + BM * cw * 4 > 160 * 1024; }
+constexpr bool alias_t2(int bmt, int cw, int cn, bool has_c2) { return !has_c2 && r0_bytes(bmt, cw, cn, has_c2) + bmt * cw * 4 > 160 * 1024; }
 #else
-constexpr bool alias_t2(int cw, int cn, bool has_c2) { return !has_c2; }
+constexpr bool alias_t2(int bmt, int cw, int cn, bool has_c2) { return !has_c2; }
 #endif
-constexpr int lds_bytes(int cw, int cn, bool has_c2) {   // 80 KiB (two per CU) | 112-144 KiB
-  const int r0 = r0_bytes(cw, cn, has_c2), t2 = BM * cw * 4;
-  return !alias_t2(cw, cn, has_c2) ? r0 + t2 : (r0 > W1B_OFF + t2 ? r0 : W1B_OFF + t2);
+constexpr int lds_bytes(int bmt, int cw, int cn, bool has_c2) {   // 80 KiB (two per CU) | 112-160 KiB
+  const int r0 = r0_bytes(bmt, cw, cn, has_c2), t2 = bmt * cw * 4;
+  return !alias_t2(bmt, cw, cn, has_c2) ? r0 + t2 : (r0 > w1b_off(bmt) + t2 ? r0 : w1b_off(bmt) + t2);
 }
-constexpr int wgs_per_cu(int cw, int cn, bool has_c2) { return lds_bytes(cw, cn, has_c2) <= 80 * 1024 ? 2 : 1; }
+constexpr int wgs_per_cu(int bmt, int cw, int cn, bool has_c2) { return bmt == 128 && lds_bytes(bmt, cw, cn, has_c2) <= 80 * 1024 ? 2 : 1; }
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 
@@ -96,18 +100,25 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES>
-__global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c64(const ChainK p) {
+template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT>
+__global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT / 128) bneck_chain_c64(const ChainK p) {
   static_assert(!HAS_C2 || CW == C, "phase 1 is written for 64-channel bottlenecks");
+  static_assert(BMT == 128 || BMT == 256, "tile height");
+  constexpr int NTHR = 2 * BMT;                     // threads: one wave per 32 rows
+  constexpr int NW = NTHR / 64;                     // waves
+  constexpr int LR = NTHR / 8;                      // rows one DMA pass of the workgroup covers (8 rows per wave instruction)
+  constexpr int STAGE = stage_bytes(BMT);
+  constexpr int W1B_OFF = w1b_off(BMT);
   constexpr int TN3 = CN / 32;
   constexpr int CS = CW / 32;                       // K slices of conv3
   constexpr int NCH = NOUT / 32;                    // groups of 32 conv3 filters
   constexpr int W3CH = CW * 128;                    // bytes of one conv3 filter group in LDS
-  constexpr bool ALIAS = alias_t2(CW, CN, HAS_C2);
-  constexpr int T2_OFF = ALIAS ? W1B_OFF : r0_bytes(CW, CN, HAS_C2);
-  constexpr int WGS = wgs_per_cu(CW, CN, HAS_C2);   // two per CU: 256 registers per wave
-  static_assert(lds_bytes(CW, CN, HAS_C2) <= 160 * 1024, "LDS budget");
-  constexpr bool W1DB = w1_double(CN, HAS_C2);
+  constexpr bool ALIAS = alias_t2(BMT, CW, CN, HAS_C2);
+  constexpr int T2_OFF = ALIAS ? W1B_OFF : r0_bytes(BMT, CW, CN, HAS_C2);
+  constexpr int WGS = wgs_per_cu(BMT, CW, CN, HAS_C2);
+  constexpr int WPS = WGS * NW / 4;                 // waves per SIMD: 2 = 256 registers per wave
+  static_assert(lds_bytes(BMT, CW, CN, HAS_C2) <= 160 * 1024, "LDS budget");
+  constexpr bool W1DB = w1_double(BMT, CN, HAS_C2);
   // The next chunk's filter DMAs are issued one at a time BETWEEN the phase-2 MFMAs where both buffers are double
   // (an LDS-DMA instruction holds the wave until the vector-memory path has taken it: as a burst of CS + CN / 32 at the top
   // of the chunk that was ~1000-2000 cycles with the matrix pipe idle; behind an MFMA it costs the difference)
@@ -116,8 +127,8 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
 #else
   constexpr bool SPREAD = W1DB;
 #endif
-  constexpr bool W1PRE = W1DB && CN <= 128 && (HAS_C2 || WGS == 1);   // conv1' fragments of a chunk requested under phase 2 (registers permitting)
-  constexpr int W3B_OFF = w3b_off(CN, HAS_C2);
+  constexpr bool W1PRE = W1DB && (HAS_C2 ? CN <= 64 || WPS == 1 : CN <= 128 && WPS == 1);   // conv1' fragments of a chunk requested under phase 2 (registers permitting)
+  constexpr int W3B_OFF = w3b_off(BMT, CN, HAS_C2);
   static_assert(!HAS_C2 || W3B_OFF + 2 * W3CH <= 2 * STAGE, "chunk buffers must fit the phase-1 stage region");
   constexpr int NRES = HAS_RES ? 4 : 0;             // residual loads per chunk and thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -132,7 +143,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int lrow = tid >> 3;                                     // 0..31 (+32 i)
+  const int lrow = tid >> 3;                                     // 0..LR-1 (+LR i)
   const int csrc = (tid & 7) ^ swz(lrow);                        // source chunk of LDS position tid & 7
   const int l31 = lane & 31, half = lane >> 5;
   const int rsw = swz(l31);
@@ -147,12 +158,12 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
   // =========================================================================================== phase 1: 3x3 conv
   if constexpr (HAS_C2) {
     f32x16 acc1[2];
-    constexpr int A_LD = BM / 32, B_LD = C / 32;
-    const int wm = wave / 2, wn = wave % 2;                      // 2 x 2 waves of 64 x 32
+    constexpr int A_LD = BMT / LR, B_LD = C / LR;
+    const int wm = wave / 2, wn = wave % 2;                      // (NW / 2) x 2 waves of 64 x 32
     TapPiece tp[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-      const int m = tile_m * BM + lrow + 32 * i;
+      const int m = tile_m * BMT + lrow + LR * i;
       unsigned pbase = 0;
       int hi0 = -(1 << 28), wi0 = 0;
       if (m < p.M) {
@@ -175,7 +186,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2), 0, p.w2_bytes, 0x00020000);
     unsigned woff[B_LD];
 #pragma unroll
-    for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((lrow + 32 * i) * (9 * C) + csrc * 4) * 4);
+    for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((lrow + LR * i) * (9 * C) + csrc * 4) * 4);
     unsigned rowoff[A_LD];
     auto set_tap = [&](int tap, int kh_i, int kw_i) {
       const unsigned tapoff = (unsigned)((kh_i * p.w + kw_i) * p.t1_ld) * 4u;
@@ -193,17 +204,17 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
     };
     auto dma_slice = [&](int kt, int stage) {
       char* a = lds + stage * STAGE + wave_u * 8 * ROWB;
-      char* b = a + BM * ROWB;
+      char* b = a + BMT * ROWB;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         const unsigned ro = rowoff[i];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * i * ROWB), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + LR * i * ROWB), 16,
                                                  (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
         if (FCP_ABLATE(p, 16) && (i & 1)) continue;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 32 * i * ROWB), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + LR * i * ROWB), 16,
                                                  (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
       }
     };
@@ -213,7 +224,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
       for (int e = 0; e < 16; ++e) acc1[i][e] = 0.f;
 
     const int aoff = (wm * 64 + l31) * ROWB;
-    const int boff = BM * ROWB + (wn * 32 + l31) * ROWB;
+    const int boff = BMT * ROWB + (wn * 32 + l31) * ROWB;
     constexpr int KT = 9 * C / 32;                               // 18 K slices
     set_tap(0, 0, 0);
     dma_slice(0, 0);
@@ -257,7 +268,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
       stage ^= 1;
     }
 
-    // ---- conv2 epilogue: fp32 tile [128][64] over the dead stages -> relu(acc * ws2 + b2) -> T2 operand image
+    // ---- conv2 epilogue: fp32 tile [BMT][64] over the dead stages -> relu(acc * ws2 + b2) -> T2 operand image
     float* Cs = smem;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -277,7 +288,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int row = (tid >> 3) + 32 * g;
+        const int row = (tid >> 3) + LR * g;
         const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * C + ccol);
         const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * C + ccol + 4);
         float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -290,7 +301,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
         u32x4_t hi, lo;
         split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
         const int q = (ccol & 31) >> 3, sw = swz(row);
-        char* trow = lds + T2_OFF + (ccol >> 5) * (BM * ROWB) + row * ROWB;
+        char* trow = lds + T2_OFF + (ccol >> 5) * (BMT * ROWB) + row * ROWB;
         *reinterpret_cast<u32x4_t*>(trow + ((q ^ sw) << 4)) = hi;
         *reinterpret_cast<u32x4_t*>(trow + (((4 + q) ^ sw) << 4)) = lo;
       }
@@ -300,12 +311,12 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
     // ---- no conv2: the operand tile is the input itself (CS slices of 128 pixels x 128 B), by LDS-DMA
     __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t1), 0, p.t1_bytes, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
-      const int m = tile_m * BM + lrow + 32 * i;
+    for (int i = 0; i < BMT / LR; ++i) {
+      const int m = tile_m * BMT + lrow + LR * i;
       const unsigned ro = m < p.M ? ((unsigned)m * (unsigned)p.t1_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
 #pragma unroll
       for (int sl = 0; sl < CS; ++sl)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(lds + T2_OFF + sl * BM * ROWB + wave_u * 8 * ROWB + 32 * i * ROWB),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(lds + T2_OFF + sl * BMT * ROWB + wave_u * 8 * ROWB + LR * i * ROWB),
                                                  16, (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(sl * 128)), 0, 0, 0);
     }
   }
@@ -313,42 +324,45 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
   // ========================================================================== chunk loop: conv3 (+x, relu) and conv1'
   __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w3), 0, p.w3_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w1n), 0, p.w1n_bytes, 0x00020000);
-  // conv3 filter group j: 32 rows x CS K slices = 4 CS pieces of 8 rows.  Wave w moves pieces w CS .. w CS + CS - 1.
+  // conv3 filter group j: 32 rows x CS K slices = 4 CS pieces of 8 rows.  Wave w moves pieces w PW3 .. w PW3 + PW3 - 1.
+  constexpr int PW3 = 4 * CS / NW;                  // per wave: CS (4 waves) | CS / 2 (8 waves)
+  constexpr int PW1 = CN / (8 * NW);                // conv1' slice: CN rows, 8 per wave instruction
+  static_assert(PW3 >= 1 && PW1 >= 1, "filter pieces per wave");
   auto dma_w3 = [&](int j, int buf) {
 #pragma unroll
-    for (int i = 0; i < CS; ++i) {
+    for (int i = 0; i < PW3; ++i) {
       if (FCP_ABLATE(p, 16) && (i & 1)) continue;
-      const int g = wave_u * CS + i, sl = g >> 2, r = (g & 3) * 8 + (lane >> 3);
+      const int g = wave_u * PW3 + i, sl = g >> 2, r = (g & 3) * 8 + (lane >> 3);
       char* dst = lds + W3B_OFF + buf * W3CH + sl * 4096 + (g & 3) * 8 * ROWB;
       const unsigned src = (unsigned)((j * 32 + r) * (CW * 4) + sl * 128 + (((lane & 7) ^ swz(r)) << 4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (__attribute__((address_space(3))) void*)dst, 16, (int)src, 0, 0, 0);
     }
   };
-  // conv1' K slice j: CN rows.  Wave w moves rows w * CN/4 + 8 i + lane / 8.
+  // conv1' K slice j: CN rows.  Wave w moves rows w * CN/NW + 8 i + lane / 8.
   auto dma_w1 = [&](int j, int buf) {
-    char* dst = lds + W1B_OFF + buf * (CN * ROWB) + wave_u * (CN / 4) * ROWB;
+    char* dst = lds + W1B_OFF + buf * (CN * ROWB) + wave_u * (CN / NW) * ROWB;
 #pragma unroll
-    for (int i = 0; i < CN / 32; ++i) {
+    for (int i = 0; i < PW1; ++i) {
       if (FCP_ABLATE(p, 16) && (i & 1)) continue;
-      const int r = wave_u * (CN / 4) + 8 * i + (lane >> 3);
+      const int r = wave_u * (CN / NW) + 8 * i + (lane >> 3);
       const unsigned src = (unsigned)(r * (NOUT * 4) + j * 128 + (((lane & 7) ^ swz(r)) << 4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + 8 * i * ROWB), 16, (int)src, 0, 0, 0);
     }
   };
-  // instruction k of {filter group j, conv1' slice j} (CS + CN / 32 per wave), for issue between the phase-2 MFMAs
-  constexpr int NDMA = CS + CN / 32;
+  // instruction k of {filter group j, conv1' slice j} (PW3 + PW1 per wave), for issue between the phase-2 MFMAs
+  constexpr int NDMA = PW3 + PW1;
   auto dma_one = [&](auto kc, int j, int buf) {
     constexpr int k = decltype(kc)::value;
     if (FCP_ABLATE(p, 16) && (k & 1)) return;       // profiling builds: half of the filter DMA instructions (wrong results)
-    if constexpr (k < CS) {
-      const int g = wave_u * CS + k, sl = g >> 2, r = (g & 3) * 8 + (lane >> 3);
+    if constexpr (k < PW3) {
+      const int g = wave_u * PW3 + k, sl = g >> 2, r = (g & 3) * 8 + (lane >> 3);
       char* dst = lds + W3B_OFF + buf * W3CH + sl * 4096 + (g & 3) * 8 * ROWB;
       const unsigned src = (unsigned)((j * 32 + r) * (CW * 4) + sl * 128 + (((lane & 7) ^ swz(r)) << 4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (__attribute__((address_space(3))) void*)dst, 16, (int)src, 0, 0, 0);
     } else {
-      constexpr int i = k - CS;
-      char* dst = lds + W1B_OFF + buf * (CN * ROWB) + wave_u * (CN / 4) * ROWB;
-      const int r = wave_u * (CN / 4) + 8 * i + (lane >> 3);
+      constexpr int i = k - PW3;
+      char* dst = lds + W1B_OFF + buf * (CN * ROWB) + wave_u * (CN / NW) * ROWB;
+      const int r = wave_u * (CN / NW) + 8 * i + (lane >> 3);
       const unsigned src = (unsigned)(r * (NOUT * 4) + j * 128 + (((lane & 7) ^ swz(r)) << 4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + 8 * i * ROWB), 16, (int)src, 0, 0, 0);
     }
@@ -368,7 +382,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
   // MFMAs beside another's epilogue); what the waves share are the filter buffers: ONE barrier per chunk.
   const int eq = lane & 3;
   const int erow0 = wave * 32 + (lane >> 2);
-  const long em0 = (long)tile_m * BM + erow0;
+  const long em0 = (long)tile_m * BMT + erow0;
   long rm[2];                                                    // residual pixel of the two items (clamped)
   unsigned so[2];                                                // byte offset of the two items in `out`, 0xFFFFFFFF past the end
 #pragma unroll
@@ -408,8 +422,8 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
     for (int sl = 0; sl < CS; ++sl)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        ah[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offH[s]);
-        al[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BM * ROWB + offL[s]);
+        ah[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BMT * ROWB + offH[s]);
+        al[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BMT * ROWB + offL[s]);
       }
   };
   if constexpr (ALIAS) {                                         // T2 shares LDS with the chunk buffers: fragments first, filters after
@@ -463,7 +477,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
     if constexpr (!ALIAS) {
       if (j == 0) read_a2();
     }
-    constexpr int BG = (CS <= 4 && (HAS_C2 || WGS == 1)) ? CS : 2;   // slices of filter fragments in flight (all of them up to CS = 4, registers permitting)
+    constexpr int BG = (CS <= 4 && (HAS_C2 || WPS == 1)) ? CS : 2;   // slices of filter fragments in flight (all of them up to CS = 4, registers permitting)
     f16x8 bh[2][BG][2], bl[2][BG][2];                            // [buffer][slice in group][k-half]
     auto read_b2 = [&](int buf, int g) {
 #pragma unroll
@@ -617,7 +631,7 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
   __syncthreads();
 
   // ================================================================================ conv1' epilogue -> t1' (HBM)
-  float* Cs = smem;                                              // fp32 tile [128][64], one 64-column half at a time
+  float* Cs = smem;                                              // fp32 tile [BMT][64], one 64-column half at a time
 #pragma unroll
   for (int hh = 0; hh < CN / 64; ++hh) {
 #pragma unroll
@@ -638,8 +652,8 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int row = (tid >> 3) + 32 * g;
-      const long m = (long)tile_m * BM + row;
+      const int row = (tid >> 3) + LR * g;
+      const long m = (long)tile_m * BMT + row;
       const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ccol);
       const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ccol + 4);
       float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -665,11 +679,11 @@ __global__ void __launch_bounds__(256, wgs_per_cu(CW, CN, HAS_C2)) bneck_chain_c
   }
 }
 
-template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES>
+template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT>
 int launch(const ChainK& k, hipStream_t s) {
-  constexpr int LDS = lds_bytes(CW, CN, HAS_C2);
-  FCP_LDS_OPT_IN((&bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES>), LDS);
-  hipLaunchKernelGGL((bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES>), dim3(fcp_cdiv(k.M, BM)), dim3(256), LDS, s, k);
+  constexpr int LDS = lds_bytes(BMT, CW, CN, HAS_C2);
+  FCP_LDS_OPT_IN((&bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT>), LDS);
+  hipLaunchKernelGGL((bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT>), dim3(fcp_cdiv(k.M, BMT)), dim3(2 * BMT), LDS, s, k);
   FCP_LAUNCH_OK();
   return 0;
 }
@@ -721,12 +735,17 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   k.ablate = 0;
 #endif
   hipStream_t s = (hipStream_t)stream;
+  // tile height: 128 pixels / 4 waves (two independent workgroups per CU drift against each other: one's MFMAs beside the
+  // other's epilogue); d->tile_m = 256 asks for the 8-wave form where the operand tile fits LDS and two waves per SIMD fit
+  // the registers (same bits; measured 0-6 % slower: what halving the filter traffic gains, one barrier domain of eight
+  // waves loses — profiles/r03_probes.md)
+  const bool big = d->tile_m == 256;
   switch (variant) {
-    case 1: return launch<64, 64, 256, true, true>(k, s);
-    case 2: return launch<128, 64, 256, true, true>(k, s);
-    case 3: return launch<128, 128, 512, false, true>(k, s);
-    case 5: return launch<256, 256, 1024, false, true>(k, s);
-    case 6: return launch<256, 128, 512, false, true>(k, s);
-    default: return launch<64, 128, 256, false, false>(k, s);
+    case 1: return big ? launch<64, 64, 256, true, true, 256>(k, s) : launch<64, 64, 256, true, true, 128>(k, s);
+    case 2: return big ? launch<128, 64, 256, true, true, 256>(k, s) : launch<128, 64, 256, true, true, 128>(k, s);
+    case 3: return big ? launch<128, 128, 512, false, true, 256>(k, s) : launch<128, 128, 512, false, true, 128>(k, s);
+    case 5: return launch<256, 256, 1024, false, true, 128>(k, s);
+    case 6: return launch<256, 128, 512, false, true, 128>(k, s);     // CN = 256: 128 accumulator registers, one wave per SIMD only
+    default: return big ? launch<64, 128, 256, false, false, 256>(k, s) : launch<64, 128, 256, false, false, 128>(k, s);
   }
 }

@@ -402,8 +402,11 @@ def chain_supported(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, r
     return one(pc3, 128, 256) and one(pc1n, 256, 64)
 
 
+CHAIN_TILE_M = int(os.environ.get("FCP_CHAIN_TILE_M", "0"))   # 0 / 128: 4-wave tiles of 128 pixels; 256: 8-wave tiles where they fit
+
+
 def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, t1: Act, res: Act | None,
-                     out: Act | None = None, t1n: Act | None = None):
+                     out: Act | None = None, t1n: Act | None = None, tile_m: int | None = None):
     """One launch for  out = relu(conv3(relu(conv2(t1))) [+ res]),  t1n = relu(conv1n(out))  (BatchNorm folded): conv2 /
     conv3 of a bottleneck and conv1 of the next block; ``pc2`` None: the pair forms (no conv2, see ``chain_supported``).
     Bit-identical to the separate ``conv`` calls.  Returns (out, t1n), both split32."""
@@ -422,7 +425,8 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
         # FCP_BOUNDARY=torch: the registered custom op allocates and returns both tensors
         o, t = T.load().bottleneck_chain(t1.buf, t1.c0, None if res is None else res.buf, 0 if res is None else res.c0,
                                          opt(pc2, "w"), opt(pc2, "wscale"), opt(pc2, "bias"), pc3.w, pc3.wscale, pc3.bias,
-                                         pc1n.w, pc1n.wscale, pc1n.bias, pc3.cin, pc3.cout, pc1n.cout)
+                                         pc1n.w, pc1n.wscale, pc1n.bias, pc3.cin, pc3.cout, pc1n.cout,
+                                         CHAIN_TILE_M if tile_m is None else tile_m)
         out, t1n = Act(o, fmt=1), Act(t, fmt=1)
     else:
         if out is None:
@@ -438,6 +442,7 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
         d.w1n, d.ws1n, d.b1n = N.ptr(pc1n.w), N.ptr(pc1n.wscale), N.ptr(pc1n.bias)
         d.n, d.h, d.w, d.c, d.cn, d.nout = t1.n, t1.h, t1.w, pc3.cin, pc1n.cout, pc3.cout
         d.t1_ld, d.res_ld, d.out_ld, d.t1n_ld = t1.ld, (res.ld if res is not None else 0), out.ld, t1n.ld
+        d.tile_m = CHAIN_TILE_M if tile_m is None else tile_m
         N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
     if timing is not None:
         e1.record()

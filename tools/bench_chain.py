@@ -1,4 +1,5 @@
 """Fused bottleneck chain vs the three stand-alone convs at the bench shape (batch 64, 160x160): us per launch.
+FCP_CHAIN_TILE_M=256 times the 8-wave / 256-pixel tiles (where supported) instead of the 4-wave ones.
 FCP_CHAIN_ABLATE (profiling builds: FCP_BUILD_PROFILING=1 python face-crop-plus_amd/build_native.py --force)
 attributes the chain's time: 1 no out stores, 2 no residual loads, 4 no phase-1 loop, 8 no chunk loop."""
 import os, sys
