@@ -119,13 +119,18 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   constexpr int WPS = WGS * NW / 4;                 // waves per SIMD: 2 = 256 registers per wave
   static_assert(lds_bytes(BMT, CW, CN, HAS_C2) <= 160 * 1024, "LDS budget");
   constexpr bool W1DB = w1_double(BMT, CN, HAS_C2);
-  // The next chunk's filter DMAs are issued one at a time BETWEEN the phase-2 MFMAs where both buffers are double
-  // (an LDS-DMA instruction holds the wave until the vector-memory path has taken it: as a burst of CS + CN / 32 at the top
-  // of the chunk that was ~1000-2000 cycles with the matrix pipe idle; behind an MFMA it costs the difference)
-#ifdef FCP_CHAIN_BURST
+  // The next chunk's filter DMAs: one at a time BETWEEN the phase-2 MFMAs, or as a burst at the top of the chunk.  An LDS-DMA
+  // instruction holds its wave until the vector-memory path has taken it.  With ONE wave per SIMD (the one-workgroup pair
+  // forms) a burst of CS + CN / 32 of them is ~1000-2000 cycles with the matrix pipe idle, and spreading them wins (layer-3
+  // pair 451 vs 493 us); with TWO workgroups per CU the other workgroup's wave covers a burst, while spread instructions
+  // stretch phase 2 to 5250 cycles for 768 cycles of MFMAs: the burst wins there (layer-2 pair 644 -> 525-548 us).  The
+  // conv2 forms (two per CU, few filter pieces) are 1.5 % better spread.  profiles/r03_probes.md.
+#if defined(FCP_CHAIN_BURST)
   constexpr bool SPREAD = false;
-#else
+#elif defined(FCP_CHAIN_SPREAD)
   constexpr bool SPREAD = W1DB;
+#else
+  constexpr bool SPREAD = W1DB && (HAS_C2 || WPS == 1);
 #endif
   constexpr bool W1PRE = W1DB && (HAS_C2 ? CN <= 64 || WPS == 1 : CN <= 128 && WPS == 1);   // conv1' fragments of a chunk requested under phase 2 (registers permitting)
   constexpr int W3B_OFF = w3b_off(BMT, CN, HAS_C2);
@@ -226,13 +231,30 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     const int aoff = (wm * 64 + l31) * ROWB;
     const int boff = BMT * ROWB + (wn * 32 + l31) * ROWB;
     constexpr int KT = 9 * C / 32;                               // 18 K slices
+    // Two stages: the next slice is issued inside the iteration and waited for at its end.  (FCP_CHAIN_C2_STAGES3: three
+    // stages, slices fetched TWO ahead — the third stage costs no LDS, it lies in the T2 region, which is only written by the
+    // conv2 epilogue — measured equal, 1327-1341 vs 1328-1340 us: with two workgroups per CU the other one covers the DMA
+    // round trip already; profiles/r03_probes.md.)
+#ifdef FCP_CHAIN_C2_STAGES3
+    constexpr int NST = 3;
+#else
+    constexpr int NST = 2;
+#endif
+    static_assert(NST * STAGE <= T2_OFF + BMT * C * 4, "phase-1 stages must fit region 0 + T2");
     set_tap(0, 0, 0);
     dma_slice(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (NST == 3) {
+      advance();
+      dma_slice(1, 1);
+    }
     int stage = 0;
     const int kt_end = FCP_ABLATE(p, 4) ? 0 : KT;
     for (int kt = 0; kt < kt_end; ++kt) {
+      // slice kt has landed (the one or two younger slices may still fly) and every wave is done with slice kt - 1
+      if (NST == 3 && kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
       const char* Ab = lds + stage * STAGE + aoff;
       const char* Bb = lds + stage * STAGE + boff;
       f16x8 ah[2][2], al[2][2], bh[2], bl[2];
@@ -248,9 +270,10 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (kt + 1 < KT) {
+      if (kt + NST - 1 < KT) {                                   // into the stage slice kt - 1 has just left
         advance();
-        dma_slice(kt + 1, stage ^ 1);
+        const int nstage = stage == 0 ? NST - 1 : stage - 1;     // (stage + NST - 1) % NST
+        dma_slice(kt + NST - 1, nstage);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -262,11 +285,11 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
           acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s], acc1[i], 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      stage ^= 1;
+      stage = stage + 1 == NST ? 0 : stage + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // every wave has consumed the last slice: the stages are dead
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- conv2 epilogue: fp32 tile [BMT][64] over the dead stages -> relu(acc * ws2 + b2) -> T2 operand image
     float* Cs = smem;

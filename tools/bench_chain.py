@@ -42,7 +42,7 @@ for cn in (64, 128):
           f"{t2:6.1f} + {t3:6.1f} + {t1_:6.1f} = {t2 + t3 + t1_:7.1f} us  ablate={os.environ.get('FCP_CHAIN_ABLATE', '0')}", flush=True)
 
 # ---- pair forms (no conv2)
-for (hh, nout, cn, residual) in ((80, 512, 128, True), (160, 256, 64, False)):
+for (hh, nout, cn, residual) in ((80, 512, 128, True), (80, 512, 256, True), (160, 256, 64, False)):
     pc3 = mk(nout, 128, 1)
     pc1 = mk(cn, nout, 1)
     t = E.f32_to_split32(E.Act(torch.randn(b, hh, hh, 128, device=dev).relu()))
