@@ -272,8 +272,8 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
                 (!d->res1 || (d->res1_h == d->out_h && d->res1_w == d->out_w)),
                 "conv: the halo-tile kernel needs a 3x3 / stride 1 / pad 1 conv with cin >= 64, cout <= 64 (cout %% 8 == 0) on the "
                 "fp16x3 path with a split32 input, no second source, no resized residual");
-  FCP_REQUIRE(d->tile_n == 32 || d->tile_n == 64 || d->tile_n == 128 || (big && d->tile_n == 256),
-              "conv: tile_n must be 32/64/128 (or 256 with tile_m 256)");
+  FCP_REQUIRE(d->tile_n == 32 || d->tile_n == 64 || d->tile_n == 128 || (big && (d->tile_n == 256 || d->tile_n == 192)),
+              "conv: tile_n must be 32/64/128 (or 192 / 256 with tile_m 256)");
   if (big)
     FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && !d->in_up2 && d->cout % 8 == 0 && d->tile_n >= 128,
                 "conv: 256-row tiles need the fp16x3 path on a split32 input (no cin4 / in_up2), cout %% 8 == 0, tile_n 128/256");

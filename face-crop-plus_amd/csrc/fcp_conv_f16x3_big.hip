@@ -5,7 +5,7 @@
 // v_mfma_f32_32x32x16_f16, identical accumulation order => identical results), but organised so
 // that the matrix pipe never waits for a fragment read or a DMA round trip:
 //
-//  * tile 256 x BN (BN = 256: 2x4 waves of 128x64; BN = 128: 4x2 waves of 64x64), one workgroup per
+//  * tile 256 x BN (BN = 256: 2x4 waves of 128x64; BN = 128 | 192: 4x2 waves of 64x64 | 64x96), one workgroup per
 //    CU, two waves per SIMD.  A K slice costs 48 (24) MFMAs per wave = 3072 (1536) matrix cycles per
 //    SIMD against one DMA of 64 (48) KiB: half (three quarters of) the operand bytes per FLOP of the
 //    128x128 kernel, and a whole iteration for the DMA to land.
@@ -60,9 +60,9 @@ struct ResRows {
 
 // passes [g0, g0 + NP) of the half tile
 template <int NP>
-__device__ __forceinline__ void load_res1_rows(const ConvK& p, int m_start, int m_end, int co_base, int tid, int hw, int g0, ResRows<NP>& r) {
+__device__ __forceinline__ void load_res1_rows(const ConvK& p, int m_start, int m_end, int co_base, int co_end, int tid, int hw, int g0, ResRows<NP>& r) {
   int co = co_base + (tid % E_CPR) * 8;
-  co = co < p.cout ? co : 0;                                     // inactive lanes read a valid dummy
+  co = co < co_end ? co : 0;                                     // inactive lanes read a valid dummy
   const long m0 = (long)m_start + tid / E_CPR;
 #pragma unroll
   for (int g = 0; g < NP; ++g) {
@@ -88,12 +88,12 @@ __device__ __forceinline__ void load_res1_rows(const ConvK& p, int m_start, int 
 }
 
 template <int NP>
-__device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, int m_start, int m_end, int co_base, int tid, int hw,
+__device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, int m_start, int m_end, int co_base, int co_end, int tid, int hw,
                                               int g0, const ResRows<NP>& res) {
   const int ccol = (tid % E_CPR) * 8;
   const int crow = tid / E_CPR;
   const int co = co_base + ccol;
-  if (co >= p.cout) return;
+  if (co >= co_end) return;
   const long m0 = (long)m_start + crow;
   float bias8[8], ws8[8];
 #pragma unroll
@@ -146,12 +146,12 @@ __device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, i
 }
 
 // Row-at-a-time variant (no extra registers): used by the 256-column tile, whose main loop has none to spare.
-__device__ __forceinline__ void epilogue_rows_seq(const ConvK& p, const float* Cs, int m_start, int m_end, int co_base, int tid, int hw) {
+__device__ __forceinline__ void epilogue_rows_seq(const ConvK& p, const float* Cs, int m_start, int m_end, int co_base, int co_end, int tid, int hw) {
   constexpr int CPR = 128 / 8, RPP = NT / CPR, PASSES = BMB / RPP;
   const int ccol = (tid % CPR) * 8;
   const int crow = tid / CPR;
   const int co = co_base + ccol;
-  if (co >= p.cout) return;
+  if (co >= co_end) return;
   const long m0 = (long)m_start + crow;
   float bias8[8], ws8[8];
 #pragma unroll
@@ -489,30 +489,33 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   // ---- epilogue: 128 output columns at a time through a 256 x 128 fp32 LDS tile
   float* Cs = smem;
 #pragma unroll 1
-  for (int h = 0; h < BN / 128; ++h) {
+  for (int h = 0; h < (BN + 127) / 128; ++h) {
     // The 128-column tile requests all residual rows of the half tile at once, before staging the accumulators.
     // The 256-column tile has no registers to spare (254 live in its main loop; any more and the allocator spills
     // there), so it keeps the row-at-a-time epilogue: it is the kernel of the residual-free layers.
     ResRows<E_PASSES> res;
-    if (BN == 128 && p.res1 != nullptr) load_res1_rows<E_PASSES>(p, m_start, m_end, tile_n * BN + h * 128, tid, hw, 0, res);
-    if ((wn * WTN) / 128 == h) {
-      const int cbase = wn * WTN - h * 128;
+    // a pass covers 128 columns of the tile; the 192-column tile's second pass holds only 64 of its own
+    const int co_end = (tile_n + 1) * BN < p.cout ? (tile_n + 1) * BN : p.cout;
+    if (BN == 128 && p.res1 != nullptr) load_res1_rows<E_PASSES>(p, m_start, m_end, tile_n * BN + h * 128, co_end, tid, hw, 0, res);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col0 = wn * WTN + j * 32;               // this wave's j-th 32-column tile (WTN = 96 straddles the 128-column passes)
+      if (col0 / 128 != h) continue;
+      const int cbase = col0 - h * 128;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
         if (i < tm_act)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
           for (int rr = 0; rr < 16; ++rr) {
             const int row = wm * WTM + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-            Cs[row * 128 + cbase + j * 32 + (lane & 31)] = acc[i][j][rr];
+            Cs[row * 128 + cbase + (lane & 31)] = acc[i][j][rr];
           }
     }
     __syncthreads();
     if constexpr (BN == 128)
-      epilogue_rows<E_PASSES>(p, Cs, m_start, m_end, tile_n * BN + h * 128, tid, hw, 0, res);
+      epilogue_rows<E_PASSES>(p, Cs, m_start, m_end, tile_n * BN + h * 128, co_end, tid, hw, 0, res);
     else
-      epilogue_rows_seq(p, Cs, m_start, m_end, tile_n * BN + h * 128, tid, hw);
+      epilogue_rows_seq(p, Cs, m_start, m_end, tile_n * BN + h * 128, co_end, tid, hw);
     __syncthreads();
   }
 }
@@ -561,7 +564,7 @@ int launch(ConvK k, hipStream_t s) {
 namespace fcp_conv {
 
 int launch_f16x3_big(const ConvK& k, int tile_n, hipStream_t s) {
-  return tile_n == 256 ? launch<256>(k, s) : launch<128>(k, s);
+  return tile_n == 256 ? launch<256>(k, s) : tile_n == 192 ? launch<192>(k, s) : launch<128>(k, s);
 }
 
 }  // namespace fcp_conv

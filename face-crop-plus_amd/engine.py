@@ -350,7 +350,7 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
             if halo_ok:
                 cands = ([(128, 32)] if pc.cout <= 32 else []) + [(128, 64), (1, 32)]
             if big_ok and BIG_TILES:
-                big = [(256, 128)] + ([(256, 256)] if pc.cout >= 256 else [])
+                big = [(256, 128)] + ([(256, 256)] if pc.cout >= 256 else []) + ([(256, 192)] if 128 < pc.cout <= 192 else [])
                 cands += big
                 if BALANCE_TAIL:      # the same tiles with the last dispatch round cut into shorter M-tiles (same bits)
                     cands += [(tm, tn, N.CONV_BALANCE_TAIL) for tm, tn in big]

@@ -30,7 +30,7 @@ for case in range(cases):
     m = n * oh * ow
     tiles = [(128, 64), (128, 128)] + ([(128, 32)] if cout <= 32 else [])
     if cout % 8 == 0 and cout >= 128:
-        tiles += [(256, 128)] + ([(256, 256)] if cout >= 256 else [])
+        tiles += [(256, 128)] + ([(256, 256)] if cout >= 256 else []) + ([(256, 192)] if cout in (192, 320) else [])
     if k == 3 and stride == 1 and cout <= 64 and cin >= 64 and cout % 8 == 0:
         tiles += [(1, 32)]
     if cout % 8 != 0:
