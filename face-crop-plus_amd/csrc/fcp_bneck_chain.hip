@@ -132,7 +132,20 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
 #else
   constexpr bool SPREAD = W1DB && (HAS_C2 || WPS == 1);
 #endif
-  constexpr bool W1PRE = W1DB && (HAS_C2 ? CN <= 64 || WPS == 1 : CN <= 128 && WPS == 1);   // conv1' fragments of a chunk requested under phase 2 (registers permitting)
+  // Rotated chunk loop (experiment builds, FCP_CHAIN_ROT; the one-wave-per-SIMD pair forms: 512 registers per wave): phase 3
+  // of chunk j - 1 is issued BETWEEN the phase-2 MFMAs of chunk j (phase 2 is one dependent chain on a single accumulator,
+  // phase 3 is 6 TN3 MFMAs on TN3 independent accumulators); conv1' slice j is then fetched during chunk j and the T3
+  // fragments of chunk j are read into registers at the end of chunk j.  Bit-identical (tools/fuzz_chain.py), 10 % fewer
+  // cycles per chunk in the probes (8320 -> 7490) and 7 % MORE wall time on the layer-3 pair (440 -> 471 us; the
+  // 128 -> 512 -> 256 pair 827-867 -> 820-837): not the default.  profiles/r03_probes.md.
+#ifdef FCP_CHAIN_ROT
+  constexpr bool ROT = !HAS_C2 && W1DB && SPREAD && WPS == 1 && TN3 % CS == 0;
+#else
+  constexpr bool ROT = false;
+#endif
+  constexpr int PQ = ROT ? TN3 / CS : 0;                // phase-3 MFMAs behind every phase-2 MFMA (6 TN3 against 6 CS)
+  static_assert(!ROT || (TN3 % CS == 0 && PQ >= 1), "rotated loop: TN3 must be a multiple of CS");
+  constexpr bool W1PRE = !ROT && W1DB && (HAS_C2 ? CN <= 64 || WPS == 1 : CN <= 128 && WPS == 1);   // conv1' fragments of a chunk requested under phase 2 (registers permitting)
   constexpr int W3B_OFF = w3b_off(BMT, CN, HAS_C2);
   static_assert(!HAS_C2 || W3B_OFF + 2 * W3CH <= 2 * STAGE, "chunk buffers must fit the phase-1 stage region");
   constexpr int NRES = HAS_RES ? 4 : 0;             // residual loads per chunk and thread
@@ -384,9 +397,10 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (__attribute__((address_space(3))) void*)dst, 16, (int)src, 0, 0, 0);
     } else {
       constexpr int i = k - PW3;
-      char* dst = lds + W1B_OFF + buf * (CN * ROWB) + wave_u * (CN / NW) * ROWB;
+      const int j1 = ROT ? j - 1 : j, buf1 = ROT ? (j1 & 1) : buf;       // rotated loop: slice j - 1 of the "next" index j
+      char* dst = lds + W1B_OFF + buf1 * (CN * ROWB) + wave_u * (CN / NW) * ROWB;
       const int r = wave_u * (CN / NW) + 8 * i + (lane >> 3);
-      const unsigned src = (unsigned)(r * (NOUT * 4) + j * 128 + (((lane & 7) ^ swz(r)) << 4));
+      const unsigned src = (unsigned)(r * (NOUT * 4) + j1 * 128 + (((lane & 7) ^ swz(r)) << 4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + 8 * i * ROWB), 16, (int)src, 0, 0, 0);
     }
   };
@@ -438,6 +452,8 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     }
   };
   const int nch = FCP_ABLATE(p, 8) ? 0 : NCH;
+  f16x8 pch[2], pcl[2];                                          // rotated loop: T3 fragments of the previous chunk, per k-half
+  f16x8 wx[ROT ? TN3 : 1], wy[ROT ? TN3 : 1];                    // rotated loop: conv1' fragments of the previous chunk's slice
   float ws_l = p.ws3[l31], b_l = p.b3[l31];                      // this lane's conv3 channel of chunk 0 (MFMA layout: col = lane & 31)
   f16x8 ah[CS][2], al[CS][2];                                    // phase-2 A fragments: the wave's own 32 rows of T2, [slice][k-half]
   auto read_a2 = [&]() {
@@ -460,7 +476,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   }
   asm volatile("" ::: "memory");
   dma_w3(0, 0);
-  if constexpr (W1DB) dma_w1(0, 0);
+  if constexpr (W1DB && !ROT) dma_w1(0, 0);
   asm volatile("" ::: "memory");
   if (nch > 0) load_res(0);
   __builtin_amdgcn_sched_barrier(0);
@@ -529,20 +545,59 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     f32x16 acc2;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+    // rotated loop: phase 3 of chunk j - 1 rides between the phase-2 MFMAs.  Its conv1' fragments live in two register sets
+    // X, Y of TN3: k-half 0 needs dh0 (terms 0, 2) and dl0 (term 1), k-half 1 dh1 and dl1; X = dh0 -> dl1, Y = dl0 -> dh1,
+    // each reloaded right behind the last MFMA that takes its old contents, TN3 MFMAs before its next use.
+    const bool prev = ROT && j > 0;
+    const char* w1p = lds + W1B_OFF + ((j + 1) & 1) * (CN * ROWB) + l31 * ROWB;     // conv1' slice j - 1
+    auto p3_read = [&](f16x8 (&dst)[ROT ? TN3 : 1], int off) {
+#pragma unroll
+      for (int t = 0; t < (ROT ? TN3 : 0); ++t) dst[t] = *reinterpret_cast<const f16x8*>(w1p + t * 32 * ROWB + off);
+    };
+    if constexpr (ROT) {
+      if (prev) {
+        p3_read(wx, offH[0]);
+        p3_read(wy, offL[0]);
+      }
+    }
+    auto p3_step = [&](auto mc) {                                  // MFMA m3 of phase 3 (chunk j - 1), term-major inside a k-half
+      constexpr int m3 = decltype(mc)::value;
+      constexpr int s3 = m3 / (3 * TN3), term = (m3 % (3 * TN3)) / TN3, t = m3 % TN3;
+      if constexpr (m3 == 2 * TN3) p3_read(wy, offH[1]);           // dl0 is dead: Y <- dh1
+      if constexpr (m3 == 3 * TN3) p3_read(wx, offL[1]);           // dh0 is dead: X <- dl1
+      if constexpr (s3 == 0) {
+        if constexpr (term == 0) acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pcl[0], wx[t], acc3[t], 0, 0, 0);
+        else if constexpr (term == 1) acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pch[0], wy[t], acc3[t], 0, 0, 0);
+        else acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pch[0], wx[t], acc3[t], 0, 0, 0);
+      } else {
+        if constexpr (term == 0) acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pcl[1], wy[t], acc3[t], 0, 0, 0);
+        else if constexpr (term == 1) acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pch[1], wx[t], acc3[t], 0, 0, 0);
+        else acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pch[1], wy[t], acc3[t], 0, 0, 0);
+      }
+    };
     static_for<0, CS / BG>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
       if constexpr (g + 1 < CS / BG) read_b2((g + 1) & 1, g + 1);  // next group's fragments under this group's MFMAs
       static_for<0, 2 * BG>([&](auto tc) {
         constexpr int q = decltype(tc)::value / 2, s = decltype(tc)::value % 2, sl = g * BG + q, trip = 2 * sl + s;
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[g & 1][q][s], acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
+        static_for<0, 3>([&](auto ec) {
+          constexpr int term = decltype(ec)::value;
+          if constexpr (term == 0) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
+          else if constexpr (term == 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[g & 1][q][s], acc2, 0, 0, 0);
+          else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
+          if constexpr (ROT) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (prev) static_for<0, PQ>([&](auto pc) { p3_step(std::integral_constant<int, (3 * trip + term) * PQ + decltype(pc)::value>{}); });
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
         constexpr int PER = (NDMA + 2 * CS - 1) / (2 * CS);       // DMA instructions per MFMA triple (1, or 2 where CN > 32 CS)
         if constexpr (SPREAD && trip * PER < NDMA) {
           __builtin_amdgcn_sched_barrier(0);
-          if (more) {
-            dma_one(std::integral_constant<int, trip * PER>{}, j + 1, (j + 1) & 1);
-            if constexpr (PER == 2 && trip * PER + 1 < NDMA) dma_one(std::integral_constant<int, trip * PER + 1>{}, j + 1, (j + 1) & 1);
+          // rotated loop: the conv1' pieces fetch slice j (consumed by chunk j + 1's phase 3 ride): also in the last chunk
+          if (more || (ROT && trip * PER >= PW3)) dma_one(std::integral_constant<int, trip * PER>{}, j + 1, (j + 1) & 1);
+          if constexpr (PER == 2 && trip * PER + 1 < NDMA) {
+            if (more || (ROT && trip * PER + 1 >= PW3)) dma_one(std::integral_constant<int, trip * PER + 1>{}, j + 1, (j + 1) & 1);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -607,6 +662,28 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
+    auto store_out = [&]() {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const unsigned o = so[it] == 0xFFFFFFFFu ? 0xFFFFFFFFu : so[it] + (unsigned)(j * 128);
+        __builtin_amdgcn_raw_buffer_store_b128(ohi[it], rs_out, o, 0, FCP_CHAIN_STORE_AUX);     // aux 2: nt (streamed once)
+        __builtin_amdgcn_raw_buffer_store_b128(olo[it], rs_out, o == 0xFFFFFFFFu ? o : o + 64u, 0, FCP_CHAIN_STORE_AUX);
+      }
+    };
+    if constexpr (ROT) {
+      // rotated loop: T3 of this chunk goes to registers now (the tile is overwritten by the next chunk's staging); its
+      // phase 3 rides in the next chunk's phase 2.  The chunk's `out` stores go out behind the fragment reads.
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        pch[s] = *reinterpret_cast<const f16x8*>(a3base + offH[s]);
+        pcl[s] = *reinterpret_cast<const f16x8*>(a3base + offL[s]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      store_out();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     // ---- phase 3: acc3 += T3 . W1'[:, slice j]^T, one k-half at a time (fragment registers: CN = 128 has none to spare);
     //      this chunk's `out` stores go out behind the first k-half's fragment reads
     const char* w1base = lds + W1B_OFF + (W1DB ? (j & 1) * (CN * ROWB) : 0);
@@ -625,12 +702,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
       if (s == 0) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const unsigned o = so[it] == 0xFFFFFFFFu ? 0xFFFFFFFFu : so[it] + (unsigned)(j * 128);
-          __builtin_amdgcn_raw_buffer_store_b128(ohi[it], rs_out, o, 0, FCP_CHAIN_STORE_AUX);     // aux 2: nt (streamed once)
-          __builtin_amdgcn_raw_buffer_store_b128(olo[it], rs_out, o == 0xFFFFFFFFu ? o : o + 64u, 0, FCP_CHAIN_STORE_AUX);
-        }
+        store_out();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -640,6 +712,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
         acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dl[s][t], acc3[t], 0, 0, 0);
         acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, dh[s][t], acc3[t], 0, 0, 0);
       }
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -652,6 +725,27 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (ROT) {
+    // phase 3 of the last chunk: its conv1' slice was fetched during the last chunk and has landed (wait + barrier above)
+    if (nch > 0) {
+      const char* w1l = lds + W1B_OFF + ((NCH - 1) & 1) * (CN * ROWB) + l31 * ROWB;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int t = 0; t < TN3; ++t) {
+          wx[t] = *reinterpret_cast<const f16x8*>(w1l + t * 32 * ROWB + offH[s]);
+          wy[t] = *reinterpret_cast<const f16x8*>(w1l + t * 32 * ROWB + offL[s]);
+        }
+#pragma unroll
+        for (int t = 0; t < TN3; ++t) {
+          acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pcl[s], wx[t], acc3[t], 0, 0, 0);
+          acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pch[s], wy[t], acc3[t], 0, 0, 0);
+          acc3[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pch[s], wx[t], acc3[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                                               // the conv1' buffers are reused by the fp32 tile below
+  }
 
   // ================================================================================ conv1' epilogue -> t1' (HBM)
   float* Cs = smem;                                              // fp32 tile [BMT][64], one 64-column half at a time

@@ -13,7 +13,9 @@ g = torch.Generator().manual_seed(0)
 mk = lambda co, ci, k: E.pack_conv(torch.randn(co, ci, k, k, generator=g) * (2 / (ci * k * k)) ** 0.5, torch.randn(co, generator=g) * 0.1,
                                    None, 1, k // 2, dev, precision="f16x3")
 b = 64
-for (hh, c, nout, cn, has_c2, residual) in ((160, 64, 256, 64, True, True), (80, 128, 512, 128, False, True)):
+import os
+SHAPES = {'l1': (160, 64, 256, 64, True, True), 'l2': (80, 128, 512, 128, False, True), 'l3': (40, 256, 1024, 256, False, True), 'l23': (80, 128, 512, 256, False, True)}
+for (hh, c, nout, cn, has_c2, residual) in [SHAPES[k] for k in os.environ.get('SHAPES', 'l1 l2').split()]:
     pc2 = mk(c, c, 3) if has_c2 else None
     pc3, pc1 = mk(nout, c, 1), mk(cn, nout, 1)
     t = E.f32_to_split32(E.Act(torch.randn(b, hh, hh, c, device=dev).relu()))
