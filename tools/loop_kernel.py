@@ -1,0 +1,47 @@
+"""Run ONE conv-engine launch in a loop for ~N seconds (power / clock sampling with tools/smi_sample.sh).
+    python tools/loop_kernel.py chain|pair2|pair3|big3x3|halo|stem [seconds]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from face_crop_plus_amd import engine as E
+dev = torch.device("cuda:0")
+what = sys.argv[1]
+secs = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
+g = torch.Generator().manual_seed(0)
+mk = lambda co, ci, k: E.pack_conv(torch.randn(co, ci, k, k, generator=g) * (2 / (ci * k * k)) ** 0.5, torch.randn(co, generator=g) * 0.1,
+                                   None, 1, k // 2, dev, precision="f16x3")
+sp = lambda n, h, c: E.f32_to_split32(E.Act(torch.randn(n, h, h, c, device=dev).relu()))
+b = 64
+if what == "chain":
+    pc2, pc3, pc1 = mk(64, 64, 3), mk(256, 64, 1), mk(64, 256, 1)
+    t1, x = sp(b, 160, 64), sp(b, 160, 256)
+    out, t1n = E.Act.empty(b, 160, 160, 256, dev, 1), E.Act.empty(b, 160, 160, 64, dev, 1)
+    f = lambda: E.bottleneck_chain(pc2, pc3, pc1, t1, x, out, t1n)
+elif what in ("pair2", "pair3"):
+    c, nout, cn, h = (128, 512, 128, 80) if what == "pair2" else (256, 1024, 256, 40)
+    pc3, pc1 = mk(nout, c, 1), mk(cn, nout, 1)
+    t, x = sp(b, h, c), sp(b, h, nout)
+    out, t1n = E.Act.empty(b, h, h, nout, dev, 1), E.Act.empty(b, h, h, cn, dev, 1)
+    f = lambda: E.bottleneck_chain(None, pc3, pc1, t, x, out, t1n)
+elif what == "big3x3":
+    pc = mk(256, 256, 3); x = sp(b, 80, 256); out = E.Act.empty(b, 80, 80, 256, dev, 1)
+    f = lambda: E.conv(pc, x, out, act_slope=0.0, tile_m=256, tile_n=256)
+elif what == "halo":
+    pc = mk(32, 160, 3); x = sp(1, 1024, 192); 
+    f = lambda: E.conv(pc, x.slice(0, 160), x.slice(160, 32), act_slope=0.2, tile_m=1, tile_n=32)
+elif what == "copy":
+    a = torch.empty(1 << 28, device=dev); c = torch.empty_like(a)
+    f = lambda: c.copy_(a)
+else:
+    raise SystemExit(what)
+for _ in range(3): f()
+torch.cuda.synchronize()
+t0 = time.time(); n = 0
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+while time.time() - t0 < secs:
+    for _ in range(50): f()
+    n += 50
+    torch.cuda.synchronize()
+e1.record(); torch.cuda.synchronize()
+print(f"{what}: {e0.elapsed_time(e1) / n * 1e3:.1f} us per launch over {n} launches", flush=True)
