@@ -84,7 +84,7 @@ typedef struct fcp_conv_desc {
                          (rrdb.py:78-79, _layers.py:338,:343) */
   int32_t cout, kh, kw, stride, pad;
   int32_t out_h, out_w, out_ld;
-  int32_t tile_n;     /* N tile: 32, 64 or 128 (256 with tile_m = 256); filters are padded to 128 rows */
+  int32_t tile_n;     /* N tile: 32, 64 or 128 (128, 192 or 256 with tile_m = 256); filters are padded to 128 rows */
   int32_t cin4;       /* 1: cin4 mode */
   float act_slope, alpha, alpha2;
   int32_t res1_pre, res1_ld, res1_h, res1_w, res2_ld;
