@@ -51,7 +51,18 @@ struct StemParams {
   int n, h, w, hs, ws, hp, wp, out_ld, out_fmt;
   int tiles_y, tiles_x, npatches;
   int mean[3];
+  // optional 1x1 conv 64 -> 64 (+ ReLU) on the pooled map, i.e. conv1 of the first bottleneck (HAS_C1 instantiation)
+  const char* w1;          // packed fp16x3 filter [>= 64 rows][2 slices][32 hi | 32 lo binary16] (engine.py::pack_conv)
+  const float* ws1;
+  const float* b1;
+  float* t1;               // split32 output (n, hp, wp, t1_ld)
+  int t1_ld;
 };
+
+constexpr int C1ROWS = 96;                     // the 80 pooled pixels of a patch padded to three MFMA row tiles
+constexpr int C1_BYTES = C1ROWS * 2 * 128;     // conv1 operand image: [96 rows][2 channel slices][128 B]
+constexpr int CPITCH = 68;                     // floats per pixel of conv1's fp32 staging tile (in the stem stage region)
+__device__ __forceinline__ int swz1(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain vmcnt, i.e. park every wave
 // until the pooled pixels of this patch have reached HBM and the next patch's bytes have arrived.
@@ -61,10 +72,12 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+template <bool HAS_C1>
 __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ __attribute__((aligned(16))) _Float16 inh[IN_ELEMS];   // (x - mean) as binary16: exact integers
   float* stage = smem;
+  char* c1in = reinterpret_cast<char*>(smem + NSTEM * SPITCH);      // HAS_C1: conv1's operand image (split32 rows, swizzled)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -89,6 +102,11 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
     bias8[e] = p.bias[(tid & 7) * 8 + e];
     ws8[e] = p.wscale[(tid & 7) * 8 + e];
   }
+  // HAS_C1: waves 0..5 own one 32 x 32 tile of the 96 x 64 conv1 output each (row tile wave >> 1, filters (wave & 1) * 32 ..).
+  // Its filter fragments — 2 channel slices x 2 k-halves x hi / lo, 8 KiB for the whole conv, L1-resident — are fetched per
+  // patch (the stem's 22 fragments fill the register file).  K order and term order are those of conv_igemm_f16x3_dma
+  // (slices ascending; per k-half al*bh, ah*bl, ah*bh): same bits.
+  const int c1rt = wave >> 1, c1ct = wave & 1;
 
   // this thread's share of the image patch: byte index b -> (row, byte column)
   int lrow[NLOAD], lcol[NLOAD];
@@ -222,10 +240,66 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
         char* ob = reinterpret_cast<char*>(p.out) + pixel * p.out_ld * 4 + split_chan_off(c8);
         *reinterpret_cast<u32x4_t*>(ob) = hi;
         *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
+        if constexpr (HAS_C1) {                           // the same hi / lo bytes are conv1's operand: row pp, slice c8 / 32
+          const int q = (c8 & 31) >> 3, sw = swz1(pp);
+          char* trow = c1in + pp * 256 + (c8 >> 5) * 128;
+          *reinterpret_cast<u32x4_t*>(trow + ((q ^ sw) << 4)) = hi;
+          *reinterpret_cast<u32x4_t*>(trow + (((4 + q) ^ sw) << 4)) = lo;
+        }
       } else {
         float* dst = p.out + pixel * p.out_ld + c8;
         *reinterpret_cast<f32x4*>(dst) = f32x4{m[0], m[1], m[2], m[3]};
         *reinterpret_cast<f32x4*>(dst + 4) = f32x4{m[4], m[5], m[6], m[7]};
+      }
+    }
+    if constexpr (HAS_C1) {
+      lds_barrier();                                    // conv1 operand complete; the stem stage is no longer read
+      if (c1rt < 3) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const int row = c1rt * 32 + (lane & 31), sw = swz1(row);
+        const char* arow = c1in + row * 256;
+        const char* wrow = p.w1 + (size_t)(c1ct * 32 + (lane & 31)) * 256;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+          for (int sh = 0; sh < 2; ++sh) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(wrow + sl * 128 + (2 * sh + half) * 16);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(wrow + sl * 128 + (4 + 2 * sh + half) * 16);
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + sl * 128 + (((2 * sh + half) ^ sw) << 4));
+            const f16x8 al = *reinterpret_cast<const f16x8*>(arow + sl * 128 + (((4 + 2 * sh + half) ^ sw) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+          }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int r = c1rt * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+          stage[r * CPITCH + c1ct * 32 + (lane & 31)] = acc[rr];
+        }
+      }
+      lds_barrier();                                    // conv1's fp32 tile staged
+      for (int item = tid; item < PH * PW * 8; item += NT) {
+        const int c8 = (item & 7) * 8, pp = item >> 3;
+        const int py = pp / PW, px = pp - py * PW;
+        const int oy = py0 + py, ox = px0 + px;
+        if (oy >= p.hp || ox >= p.wp) continue;
+        const float* cs = stage + pp * CPITCH + c8;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(cs), v = *reinterpret_cast<const f32x4*>(cs + 4);
+        float t[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                   // the generic epilogue's expressions (act_slope 0, alpha 1)
+          float x = t[e] * p.ws1[c8 + e] + p.b1[c8 + e];
+          x = x >= 0.f ? x : x * 0.f;
+          t[e] = x * 1.f;
+        }
+        u32x4_t hi, lo;
+        split8(f32x4{t[0], t[1], t[2], t[3]}, f32x4{t[4], t[5], t[6], t[7]}, hi, lo);
+        const long pixel = ((long)ni * p.hp + oy) * p.wp + ox;
+        char* ob = reinterpret_cast<char*>(p.t1) + pixel * p.t1_ld * 4 + split_chan_off(c8);
+        *reinterpret_cast<u32x4_t*>(ob) = hi;
+        *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
       }
     }
     lds_barrier();                                      // stage free for the next patch
@@ -234,10 +308,18 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
 
 }  // namespace
 
-extern "C" int fcp_stem7x7s2_relu_pool_u8(const uint8_t* images, int n, int h, int w, const int32_t* mean_rgb,
-                                          const void* wfrag, const float* bias, const float* wscale, float* out,
-                                          int out_ld, int out_fmt, fcp_stream_t stream) {
+extern "C" int fcp_stem7x7s2_relu_pool_conv1_u8(const uint8_t* images, int n, int h, int w, const int32_t* mean_rgb,
+                                                const void* wfrag, const float* bias, const float* wscale, float* out,
+                                                int out_ld, int out_fmt, const void* w1, const float* ws1, const float* b1,
+                                                float* t1, int t1_ld, fcp_stream_t stream) {
   FCP_REQUIRE(images && wfrag && bias && wscale && out && mean_rgb, "stem: null pointer");
+  const bool has_c1 = w1 != nullptr;
+  if (has_c1) {
+    FCP_REQUIRE(ws1 && b1 && t1, "stem + conv1: conv1 needs its scales, bias and output");
+    FCP_REQUIRE(out_fmt == 1, "stem + conv1: the pooled map must be written in split32 (its bytes are conv1's operand)");
+    FCP_REQUIRE(t1_ld >= 64 && t1_ld % 32 == 0 && ((uintptr_t)t1 & 127) == 0 && ((uintptr_t)w1 & 15) == 0,
+                "stem + conv1: misaligned conv1 filter / output view");
+  }
   FCP_REQUIRE(n > 0 && h >= 1 && w >= 1 && (long)h * w * 3 < (1L << 31), "stem: bad image size");
   FCP_REQUIRE((unsigned)out_fmt <= 1u, "stem: out_fmt must be 0 (fp32) or 1 (split32)");
   FCP_REQUIRE(out_ld >= 64 && out_ld % (out_fmt ? 32 : 4) == 0 && ((uintptr_t)out & (out_fmt ? 127 : 15)) == 0,
@@ -255,10 +337,24 @@ extern "C" int fcp_stem7x7s2_relu_pool_u8(const uint8_t* images, int n, int h, i
   FCP_REQUIRE(np < (1L << 31) && (long)n * h * w * 3 < (1L << 40), "stem: batch too large");
   p.npatches = (int)np;
   for (int c = 0; c < 3; ++c) p.mean[c] = mean_rgb[c];
-  const size_t lds = (size_t)NSTEM * SPITCH * 4;       // stem staging (the binary16 image patch is a static array)
-  FCP_LDS_OPT_IN(&stem_pool_kernel, lds);
-  const int grid = (int)(np < 256 ? np : 256);
-  hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, p);
+  p.w1 = static_cast<const char*>(w1); p.ws1 = ws1; p.b1 = b1; p.t1 = t1; p.t1_ld = t1_ld;
+  const size_t lds = (size_t)NSTEM * SPITCH * 4 + (has_c1 ? C1_BYTES : 0);   // stem staging (+ conv1's operand image); the binary16 image patch is a static array
+  const int cus = fcp_cu_count();
+  const int grid = (int)(np < cus ? np : cus);
+  if (has_c1) {
+    FCP_LDS_OPT_IN(&stem_pool_kernel<true>, lds);
+    hipLaunchKernelGGL(stem_pool_kernel<true>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, p);
+  } else {
+    FCP_LDS_OPT_IN(&stem_pool_kernel<false>, lds);
+    hipLaunchKernelGGL(stem_pool_kernel<false>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, p);
+  }
   FCP_LAUNCH_OK();
   return 0;
+}
+
+extern "C" int fcp_stem7x7s2_relu_pool_u8(const uint8_t* images, int n, int h, int w, const int32_t* mean_rgb,
+                                          const void* wfrag, const float* bias, const float* wscale, float* out,
+                                          int out_ld, int out_fmt, fcp_stream_t stream) {
+  return fcp_stem7x7s2_relu_pool_conv1_u8(images, n, h, w, mean_rgb, wfrag, bias, wscale, out, out_ld, out_fmt, nullptr, nullptr,
+                                          nullptr, nullptr, 0, stream);
 }

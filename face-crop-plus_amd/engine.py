@@ -511,9 +511,17 @@ def pack_stem_fused(weight, bn, device, cin_perm=None) -> PackedStem:
                       2 * 64 * 3 * 49)
 
 
+def stem_conv1_supported(pc1: PackedConv | None) -> bool:
+    """conv1 of the first bottleneck can ride in the stem launch: 1x1 / 1, 64 -> 64, fp16x3, folded-BN bias."""
+    return (pc1 is not None and pc1.precision == 1 and pc1.bias is not None and not pc1.cin4
+            and (pc1.cin, pc1.cout, pc1.kh, pc1.kw, pc1.stride, pc1.pad) == (64, 64, 1, 1, 1, 0))
+
+
 def stem_relu_pool_u8(ps: PackedStem, images_u8: torch.Tensor, out: Act | None = None, mean_rgb=(123, 117, 104),
-                      out_fmt: int = 1) -> Act:
-    """(n,h,w,3) uint8 -> stem conv + ReLU + max-pool, one launch; ``out`` may be a 64-channel slice."""
+                      out_fmt: int = 1, conv1: PackedConv | None = None, t1: Act | None = None):
+    """(n,h,w,3) uint8 -> stem conv + ReLU + max-pool, one launch; ``out`` may be a 64-channel slice.
+    ``conv1`` (see ``stem_conv1_supported``): the same launch also computes ``t1 = relu(conv1(pooled))`` (split32) and
+    returns ``(out, t1)`` — bit-identical to ``conv(conv1, out, act_slope=0.0, out_fmt=1)``."""
     assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[3] == 3 and images_u8.is_contiguous()
     n, h, w, _ = images_u8.shape
     hs, ws = (h - 1) // 2 + 1, (w - 1) // 2 + 1
@@ -526,16 +534,28 @@ def stem_relu_pool_u8(ps: PackedStem, images_u8: torch.Tensor, out: Act | None =
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    N.check(N.lib().fcp_stem7x7s2_relu_pool_u8(N.ptr(images_u8), n, h, w, mean, N.ptr(ps.wfrag), N.ptr(ps.bias),
-                                               N.ptr(ps.wscale), out.ptr(), out.ld, out.fmt, N.stream_ptr()),
-            "fcp_stem7x7s2_relu_pool_u8")
+    flops = ps.flops_per_pixel * n * hs * ws
+    if conv1 is not None:
+        assert stem_conv1_supported(conv1) and out.fmt == 1, "stem + conv1: 1x1 64 -> 64 fp16x3 conv on a split32 pooled map"
+        if t1 is None:
+            t1 = Act.empty(n, hp, wp, 64, images_u8.device, 1)
+        assert t1.fmt == 1 and (t1.n, t1.h, t1.w, t1.c) == (n, hp, wp, 64)
+        flops += conv1.flops_per_pixel * n * hp * wp
+        N.check(N.lib().fcp_stem7x7s2_relu_pool_conv1_u8(N.ptr(images_u8), n, h, w, mean, N.ptr(ps.wfrag), N.ptr(ps.bias),
+                                                         N.ptr(ps.wscale), out.ptr(), out.ld, out.fmt, N.ptr(conv1.w),
+                                                         N.ptr(conv1.wscale), N.ptr(conv1.bias), t1.ptr(), t1.ld, N.stream_ptr()),
+                "fcp_stem7x7s2_relu_pool_conv1_u8")
+    else:
+        N.check(N.lib().fcp_stem7x7s2_relu_pool_u8(N.ptr(images_u8), n, h, w, mean, N.ptr(ps.wfrag), N.ptr(ps.bias),
+                                                   N.ptr(ps.wscale), out.ptr(), out.ld, out.fmt, N.stream_ptr()),
+                "fcp_stem7x7s2_relu_pool_u8")
     if timing is not None:
         e1.record()
-        timing.append((e0, e1, ps.flops_per_pixel * n * hs * ws))
+        timing.append((e0, e1, flops))
     if ConvStats.enabled:
-        ConvStats.flops += ps.flops_per_pixel * n * hs * ws
+        ConvStats.flops += flops
         ConvStats.launches += 1
-    return out
+    return out if conv1 is None else (out, t1)
 
 
 def f32nchw_to_nhwc4(images: torch.Tensor, sub=(0.0, 0.0, 0.0), div: float = 1.0) -> Act:

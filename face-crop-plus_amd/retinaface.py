@@ -39,6 +39,7 @@ class RetinaFace:
         self._p = None
         self.precision = 0
         self.fused_stem = os.environ.get("FCP_FUSED_STEM", "1") != "0"   # fp16x3 path: uint8 -> stem + pool in one launch
+        self.fused_stem_conv1 = os.environ.get("FCP_FUSED_STEM_CONV1", "1") != "0"   # ... + layer1.0.conv1 in the same launch
         # The network runs on the two halves of a batch concurrently, on two HIP streams: the tail wave of one
         # half's launch (layers 3-4 fill only ~78 % of their last round of workgroups) overlaps the head of the
         # other's.  Images are independent, so the result is bit-identical to the single-stream pass.
@@ -131,17 +132,23 @@ class RetinaFace:
         # fp16x3 path: activations between convs live in the "split32" format (hi/lo binary16 planes per 32
         # channels, same bytes as fp32) so every consumer conv copies its operand instead of converting it
         f = 1 if self.precision == 1 else 0
+        stem_t1 = None
         if images_u8 is not None and "stem_fused" in p:
             n, h, w, _ = images_u8.shape
             hp, wp = ((h - 1) // 2) // 2 + 1, ((w - 1) // 2) // 2 + 1
             cat = E.Act.empty(n, hp, wp, 128, images_u8.device, f)                   # [conv2 out | pooled stem]
-            x = E.stem_relu_pool_u8(p["stem_fused"], images_u8, cat.slice(64, 64))
+            c1 = p["blocks"][0]["c1"]
+            if self.fused_stem_conv1 and f == 1 and E.stem_conv1_supported(c1):
+                # ... and conv1 of layer1.0 in the same launch: the pooled map is written (downsample branch) but not re-read
+                x, stem_t1 = E.stem_relu_pool_u8(p["stem_fused"], images_u8, cat.slice(64, 64), conv1=c1)
+            else:
+                x = E.stem_relu_pool_u8(p["stem_fused"], images_u8, cat.slice(64, 64))
         else:
             x = E.conv(p["stem"], x4, act_slope=0.0, out_fmt=f)
             cat = E.Act.empty(x.n, (x.h + 1) // 2, (x.w + 1) // 2, 2 * x.c, x.buf.device, f)
             x = E.maxpool3x3s2(x, cat.slice(x.c, x.c))
         feats = []
-        blocks, pre = p["blocks"], None
+        blocks, pre = p["blocks"], stem_t1
         chain = bool(f) and self.fused_chain
         for bi, blk in enumerate(blocks):
             o = pre if pre is not None else E.conv(blk["c1"], x, act_slope=0.0, out_fmt=f)

@@ -193,6 +193,16 @@ int fcp_maxpool3x3s2_split32(const float* in, float* out, int n, int h, int w, i
 int fcp_stem7x7s2_relu_pool_u8(const uint8_t* images, int n, int h, int w, const int32_t* mean_rgb,
                                const void* wfrag, const float* bias, const float* wscale, float* out,
                                int out_ld, int out_fmt, fcp_stream_t stream);
+/* The same launch continued by conv1 of the first bottleneck (torchvision Bottleneck.forward: relu(bn1(conv1(x))),
+ * a 1x1 conv 64 -> 64 on the pooled map; retinaface.py:93-99): t1 = relu(conv1x1(pooled) * ws1 + b1), written as a
+ * split32 tensor (n, hp, wp, t1_ld).  The pooled map is still written (the block's downsample branch reads it) but not
+ * read back: its hi / lo bytes are conv1's operand while they are still in LDS.  w1: the conv's packed precision-1
+ * filter (engine.py::pack_conv: >= 64 rows of [2 channel slices][32 hi | 32 lo binary16]); out_fmt must be 1.  Same K
+ * and term order as fcp_conv2d_nhwc_f32 on the stored map: bit-identical to the two launches.  w1 == NULL: the plain stem. */
+int fcp_stem7x7s2_relu_pool_conv1_u8(const uint8_t* images, int n, int h, int w, const int32_t* mean_rgb,
+                                     const void* wfrag, const float* bias, const float* wscale, float* out,
+                                     int out_ld, int out_fmt, const void* w1, const float* ws1, const float* b1,
+                                     float* t1, int t1_ld, fcp_stream_t stream);
 /* Format converters between fp32 NHWC and split32 (npix pixels of c channels, c % 32 == 0). */
 int fcp_f32_to_split32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream);
 int fcp_split32_to_f32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream);

@@ -387,6 +387,32 @@ def test_fused_stem_pool(n, h, w, device, precision):
     assert (sep.nchw().cpu() - out.nchw().cpu()).abs().max().item() <= _tol(ref)
 
 
+@pytest.mark.parametrize("n,h,w", [(1, 64, 64), (2, 75, 131), (3, 160, 96), (1, 9, 11), (2, 128, 640)])
+def test_fused_stem_pool_conv1(n, h, w, device):
+    """The stem launch continued by layer1.0.conv1 (1x1 64 -> 64 + BN + ReLU on the pooled map): the pooled map and t1 must
+    have the bits of the two separate launches (same hi / lo operand bytes, same K and term order, same epilogue expressions);
+    odd sizes, partial patches, a slice output for the pooled map."""
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(n * 977 + h * 3 + w)
+    img = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8).to(device)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 12
+    bn = lambda c: {"weight": torch.rand(c, generator=g) + 0.5, "bias": torch.randn(c, generator=g) * 0.1,
+                    "running_mean": torch.randn(c, generator=g) * 0.1, "running_var": torch.rand(c, generator=g) + 0.5}
+    ps = E.pack_stem_fused(wt, bn(64), device)
+    pc1 = E.pack_conv(torch.randn(64, 64, 1, 1, generator=g) / 8, None, bn(64), 1, 0, device, precision="f16x3")
+    assert E.stem_conv1_supported(pc1)
+    hp, wp = ((h - 1) // 2) // 2 + 1, ((w - 1) // 2) // 2 + 1
+    cat_a, cat_b = E.Act.empty(n, hp, wp, 128, device, 1), E.Act.empty(n, hp, wp, 128, device, 1)
+    cat_a.buf.zero_(); cat_b.buf.zero_()
+    pooled = E.stem_relu_pool_u8(ps, img, cat_a.slice(64, 64))
+    t1_sep = E.conv(pc1, pooled, act_slope=0.0, out_fmt=1)
+    pooled_f, t1_f = E.stem_relu_pool_u8(ps, img, cat_b.slice(64, 64), conv1=pc1)
+    torch.cuda.synchronize()
+    assert torch.equal(cat_a.buf, cat_b.buf), "pooled stem map differs"
+    assert t1_f.fmt == 1 and torch.equal(t1_f.buf, t1_sep.buf), "fused conv1 differs from the separate launch"
+    assert float(t1_f.nchw().abs().max()) > 0
+
+
 def test_conv_randomized_shapes(device, precision):
     """Seeded sweep over geometry / epilogue / format combinations (every tile the shape admits) against torch fp32."""
     from face_crop_plus_amd import engine as E
