@@ -64,16 +64,30 @@ __global__ void __launch_bounds__(256) bise_preprocess_kernel(const uint8_t* __r
   }
 }
 
-// one workgroup per (image, 64-channel group): mean over h*w of an NHWC tensor slice
+// one workgroup per (image, 64-channel group): mean over h*w of an NHWC tensor slice.  Wave `part` sums the pixels part,
+// part + 4, ... in ascending order and the four partial sums are added in order: that order is kept (the labels it feeds are
+// held to the reference fixture bit for bit), but 32 loads are in flight per lane before the first add — as a plain
+// load-add loop the 1024-pixel chains of BiSeNet's 64 x 64 feature map took 317 us of exposed HBM latency for 134 MB.
 __global__ void __launch_bounds__(256) avgpool_kernel(const float* __restrict__ in, int hw, int c, int ld,
                                                       float* __restrict__ out) {
   __shared__ float red[4][64];
   const int img = blockIdx.x, cg = blockIdx.y;
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int ch = cg * 64 + lane;
+  constexpr int U = 32;
   float acc = 0.f;
-  if (ch < c)
-    for (int p = part; p < hw; p += 4) acc += in[((long)img * hw + p) * ld + ch];
+  if (ch < c) {
+    const float* base = in + (long)img * hw * ld + ch;
+    int p = part;
+    for (; p + 4 * (U - 1) < hw; p += 4 * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = base[(long)(p + 4 * u) * ld];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += v[u];
+    }
+    for (; p < hw; p += 4) acc += base[(long)p * ld];
+  }
   red[part][lane] = acc;
   __syncthreads();
   if (part == 0 && ch < c) out[(long)img * c + ch] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)hw;
@@ -160,16 +174,36 @@ __global__ void __launch_bounds__(256) parse_tail_kernel(const float* __restrict
   }
 }
 
+// per-face class histogram.  Sixteen replicas of the 32-bin histogram in LDS (thread t uses replica t & 15): a face is
+// mostly one or two classes, and 256 threads adding to ONE LDS word serialise (64 us per 256 x 256 face with a single
+// histogram); integer counts, so the result does not depend on the order.
 __global__ void __launch_bounds__(256) label_hist_kernel(const uint8_t* __restrict__ labels, int hw, int ncls,
                                                          int* __restrict__ counts) {
-  __shared__ int hist[32];
+  __shared__ int hist[16][33];
   const int fi = blockIdx.x;
-  if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < 16 * 33; i += blockDim.x) (&hist[0][0])[i] = 0;
   __syncthreads();
   const uint8_t* l = labels + (long)fi * hw;
-  for (int p = threadIdx.x; p < hw; p += blockDim.x) atomicAdd(&hist[l[p] & 31], 1);
+  int* mine = hist[threadIdx.x & 15];
+  int p = threadIdx.x * 4;
+  if ((hw & 3) == 0 && (((uintptr_t)l) & 3) == 0) {
+    for (; p < hw; p += blockDim.x * 4) {                       // four labels per load
+      const unsigned v = *reinterpret_cast<const unsigned*>(l + p);
+      atomicAdd(&mine[v & 31], 1);
+      atomicAdd(&mine[(v >> 8) & 31], 1);
+      atomicAdd(&mine[(v >> 16) & 31], 1);
+      atomicAdd(&mine[(v >> 24) & 31], 1);
+    }
+  } else {
+    for (int q = threadIdx.x; q < hw; q += blockDim.x) atomicAdd(&mine[l[q] & 31], 1);
+  }
   __syncthreads();
-  if (threadIdx.x < ncls) counts[(long)fi * ncls + threadIdx.x] = hist[threadIdx.x];
+  if (threadIdx.x < ncls) {
+    int t = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += hist[r][threadIdx.x];
+    counts[(long)fi * ncls + threadIdx.x] = t;
+  }
 }
 
 __global__ void __launch_bounds__(256) label_mask_kernel(const uint8_t* __restrict__ labels, long total,
