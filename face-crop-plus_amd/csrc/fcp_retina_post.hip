@@ -13,6 +13,8 @@ namespace {
 constexpr int DEC_THREADS = 1024;
 constexpr int NMS_THREADS = 1024;
 constexpr int SORT_LDS_KEYS = 8192;  // 64 KiB of 8-byte keys
+constexpr int NMS_ALIVE_WORDS = SORT_LDS_KEYS - 256;   // alive bitmap of the greedy pass: 64 candidates per word
+constexpr int NMS_MAX_CAP = NMS_ALIVE_WORDS * 64;      // 507 904 candidates per image (a 2800^2 frame has 322 k priors)
 
 struct Levels {
   int h[3], w[3], start[4];
@@ -29,7 +31,7 @@ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; 
 // loads exposed, 45 us for a batch of 64 at 640^2 = 1.5 TB/s.)  The head maps of one image (1-2.75 MB) stay in L2 between
 // the passes.
 // ---------------------------------------------------------------------------
-constexpr int DEC_MAX_ROUNDS = 64;      // priors per image <= 65536 (the NMS kernel's limit as well)
+constexpr int DEC_MAX_ROUNDS = 64;      // rounds per span (one pass bit per round in a 64-bit register)
 
 struct Decoded {
   float score, box[4], ldm[10];
@@ -92,70 +94,79 @@ __global__ void __launch_bounds__(DEC_THREADS) retina_decode_kernel(
   const int img = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int P = lv.start[3];
-  const int rounds = (P + DEC_THREADS - 1) / DEC_THREADS;
+  const int rounds_all = (P + DEC_THREADS - 1) / DEC_THREADS;
+  __shared__ int s_total;
+  int total = 0;                                     // candidates of the earlier spans (workgroup-uniform)
 
-  // ---- pass 1: scores only
-  unsigned long long passbits = 0ull;               // bit r: this thread's prior of round r passes (rounds <= 64)
-  for (int r = 0; r < rounds; ++r) {
-    const int p = r * DEC_THREADS + tid;
-    bool pass = false;
-    if (p < P) {
+  // spans of up to 64 rounds (65536 priors): one span for every size up to ~1248^2, more for larger frames
+  for (int r0 = 0; r0 < rounds_all; r0 += DEC_MAX_ROUNDS) {
+    const int rounds = min(DEC_MAX_ROUNDS, rounds_all - r0);
+    // ---- pass 1: scores only
+    unsigned long long passbits = 0ull;               // bit r: this thread's prior of round r0 + r passes
+    for (int r = 0; r < rounds; ++r) {
+      const int p = (r0 + r) * DEC_THREADS + tid;
+      bool pass = false;
+      if (p < P) {
+        int l, cell, a;
+        const float* hp = head_cell(head0, head1, head2, lv, img, p, l, cell, a);
+        pass = face_score(hp, a) > thr;
+      }
+      passbits |= pass ? (1ull << r) : 0ull;
+      const unsigned long long bal = __ballot(pass);
+      if (lane == 0) cnt[r * NWAVE + wave] = __popcll(bal);
+    }
+    __syncthreads();
+    // ---- exclusive prefix over (round, wave): one wave, 64 entries at a time
+    if (wave == 0) {
+      int carry = total;
+      const int n = rounds * NWAVE;
+      for (int base = 0; base < n; base += 64) {
+        const int idx = base + lane;
+        const int v = idx < n ? cnt[idx] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(incl, o);
+          if (lane >= o) incl += t;
+        }
+        if (idx < n) cnt[idx] = carry + incl - v;
+        carry += __shfl(incl, 63);
+      }
+      if (lane == 0) s_total = carry;
+    }
+    __syncthreads();
+    total = s_total;
+    // ---- pass 2: decode and write the survivors (and everything, when the dense outputs are requested)
+    for (int r = 0; r < rounds; ++r) {
+      const int p = (r0 + r) * DEC_THREADS + tid;
+      const bool pass = (passbits >> r) & 1ull;
+      const unsigned long long bal = __ballot(pass);
+      if (p >= P || (!pass && dense_score == nullptr)) continue;
       int l, cell, a;
       const float* hp = head_cell(head0, head1, head2, lv, img, p, l, cell, a);
-      pass = face_score(hp, a) > thr;
-    }
-    passbits |= pass ? (1ull << r) : 0ull;
-    const unsigned long long bal = __ballot(pass);
-    if (lane == 0) cnt[r * NWAVE + wave] = __popcll(bal);
-  }
-  __syncthreads();
-  // ---- exclusive prefix over (round, wave): one wave, 64 entries at a time
-  if (wave == 0) {
-    int carry = 0;
-    const int n = rounds * NWAVE;
-    for (int base = 0; base < n; base += 64) {
-      const int idx = base + lane;
-      const int v = idx < n ? cnt[idx] : 0;
-      int incl = v;
+      Decoded dc;
+      decode_prior(hp, lv, l, cell, a, img_h, img_w, v0, v1, dc);
+      if (dense_score != nullptr) {
+        const long d = (long)img * P + p;
+        dense_score[d] = dc.score;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
+        for (int k = 0; k < 4; ++k) dense_box[d * 4 + k] = dc.box[k];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) dense_ldm[d * 10 + k] = dc.ldm[k];
       }
-      if (idx < n) cnt[idx] = carry + incl - v;
-      carry += __shfl(incl, 63);
+      if (pass) {
+        const long d = (long)img * P + cnt[r * NWAVE + wave] + __popcll(bal & ((1ull << lane) - 1ull));
+        cand_score[d] = dc.score;
+        cand_prior[d] = p;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cand_box[d * 4 + k] = dc.box[k];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) cand_ldm[d * 10 + k] = dc.ldm[k];
+      }
     }
-    if (lane == 0) cand_count[img] = carry;
+    __syncthreads();                                  // cnt and s_total are rewritten by the next span
   }
-  __syncthreads();
-  // ---- pass 2: decode and write the survivors (and everything, when the dense outputs are requested)
-  for (int r = 0; r < rounds; ++r) {
-    const int p = r * DEC_THREADS + tid;
-    const bool pass = (passbits >> r) & 1ull;
-    const unsigned long long bal = __ballot(pass);
-    if (p >= P || (!pass && dense_score == nullptr)) continue;
-    int l, cell, a;
-    const float* hp = head_cell(head0, head1, head2, lv, img, p, l, cell, a);
-    Decoded dc;
-    decode_prior(hp, lv, l, cell, a, img_h, img_w, v0, v1, dc);
-    if (dense_score != nullptr) {
-      const long d = (long)img * P + p;
-      dense_score[d] = dc.score;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dense_box[d * 4 + k] = dc.box[k];
-#pragma unroll
-      for (int k = 0; k < 10; ++k) dense_ldm[d * 10 + k] = dc.ldm[k];
-    }
-    if (pass) {
-      const long d = (long)img * P + cnt[r * NWAVE + wave] + __popcll(bal & ((1ull << lane) - 1ull));
-      cand_score[d] = dc.score;
-      cand_prior[d] = p;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) cand_box[d * 4 + k] = dc.box[k];
-#pragma unroll
-      for (int k = 0; k < 10; ++k) cand_ldm[d * 10 + k] = dc.ldm[k];
-    }
-  }
+  if (tid == 0) cand_count[img] = total;
 }
 
 // ---------------------------------------------------------------------------
@@ -258,10 +269,10 @@ __global__ void __launch_bounds__(NMS_THREADS) retina_nms_kernel(
   __syncthreads();
 
   // ---- 4. tiled greedy NMS.  LDS reuse: alive bitmap (Kp/64 words) then kept-box tile.
-  unsigned long long* alive = lkeys;                       // up to 1024 words
-  float* tile = reinterpret_cast<float*>(lkeys + 1024);    // 64 * 5 floats
+  unsigned long long* alive = lkeys;                                   // up to NMS_ALIVE_WORDS words
+  float* tile = reinterpret_cast<float*>(lkeys + NMS_ALIVE_WORDS);     // 64 * 5 floats
   int* tile_n = reinterpret_cast<int*>(tile + 64 * 5);
-  const int nwords = Kp >> 6;
+  const int nwords = (K + 63) >> 6;
   for (int wd = tid; wd < nwords; wd += NMS_THREADS) {
     const int lo = wd << 6;
     unsigned long long m = 0ull;
@@ -429,9 +440,6 @@ extern "C" int fcp_retina_decode(const float* head0, const float* head1, const f
   FCP_REQUIRE(head0 && head1 && head2, "retina_decode: null head pointer");
   FCP_REQUIRE(cand_score && cand_box && cand_ldm && cand_prior && cand_count, "retina_decode: null output");
   FCP_REQUIRE(n > 0 && img_h > 0 && img_w > 0, "retina_decode: bad sizes");
-  FCP_REQUIRE(2L * ((img_h + 7) / 8) * ((img_w + 7) / 8) + 2L * ((img_h + 15) / 16) * ((img_w + 15) / 16) +
-                  2L * ((img_h + 31) / 32) * ((img_w + 31) / 32) <= 65536,
-              "retina_decode: more than 65536 priors per image (the per-image NMS is limited to that too)");
   FCP_REQUIRE((dense_score == nullptr) == (dense_box == nullptr) && (dense_box == nullptr) == (dense_ldm == nullptr),
               "retina_decode: dense outputs must be all set or all NULL");
   Levels lv;
@@ -456,7 +464,7 @@ extern "C" int fcp_retina_nms_select(const float* cand_score, const float* cand_
   FCP_REQUIRE(cand_score && cand_box && cand_count && workspace, "retina_nms: null input");
   FCP_REQUIRE(keep_pos && keep_count && sel_pos && sel_count, "retina_nms: null output");
   FCP_REQUIRE(n > 0 && cap > 0, "retina_nms: bad sizes");
-  FCP_REQUIRE(cap <= 65536, "retina_nms: capacity above 65536 candidates per image is not supported");
+  FCP_REQUIRE(cap <= NMS_MAX_CAP, "retina_nms: capacity above %d candidates per image is not supported", NMS_MAX_CAP);
   FCP_REQUIRE(strategy >= 0 && strategy <= 2, "Unsupported startegy: %d", strategy);
   FCP_REQUIRE(((uintptr_t)cand_box & 15) == 0 && ((uintptr_t)workspace & 7) == 0, "retina_nms: misaligned buffers");
   const int cap_p2 = pow2_ceil(cap);

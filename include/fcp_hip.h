@@ -236,7 +236,7 @@ int fcp_retina_decode(const float* head0, const float* head1, const float* head2
  * (retinaface.py:270-298), followed by take_by_strategy (retinaface.py:363-408).
  * strategy: 0 = all, 1 = best, 2 = largest.
  * workspace: fcp_retina_nms_workspace_bytes(n, cap) bytes (sort keys + sorted
- * boxes), cap = candidate capacity (stride of the cand_* arrays, <= 65536).  Outputs: keep_pos (n,cap) int32 = candidate positions of
+ * boxes), cap = candidate capacity (stride of the cand_* arrays, <= 507904).  Outputs: keep_pos (n,cap) int32 = candidate positions of
  * the kept boxes in keep order, keep_count (n); sel_pos (n,cap) / sel_count (n)
  * = the positions take_by_strategy selects (for "all" identical to keep). */
 int64_t fcp_retina_nms_workspace_bytes(int n, int cap);

@@ -81,6 +81,45 @@ def test_priors_analytic_match_reference(device):
     assert np.array_equal(dl.cpu().numpy()[0, :, 1], pri[:, 1] * f(h))
 
 
+@pytest.mark.parametrize("h,w,n", [(1600, 1200, 2), (2048, 2048, 1)])
+def test_decode_frames_above_65536_priors(h, w, n, device):
+    """Frames whose prior count needs more than one 64-round span of the decode kernel (78 800 / 172 032 priors):
+    dense decode vs the oracle, compaction in ascending prior order, and the NMS stage on that capacity."""
+    rng = np.random.default_rng(h + w)
+    pri = R.prior_box(h, w)
+    P = pri.shape[0]
+    assert P > 65536
+    logits = rng.normal(0, 2.0, (n, P, 2)).astype(np.float32)
+    loc = rng.normal(0, 1.0, (n, P, 4)).astype(np.float32)
+    ldm = rng.normal(0, 1.0, (n, P, 10)).astype(np.float32)
+    heads = _heads_from_raw(logits, loc, ldm, h, w, device)
+    thr = 0.9
+    cs, cb, cl, cp, cc, ds, db, dl = _decode(heads, n, h, w, thr, device)
+    eb, el = R.decode(None, loc, ldm, pri, h, w)
+    es = torch.softmax(torch.from_numpy(logits), -1)[..., 1].numpy()
+    np.testing.assert_allclose(ds.cpu().numpy(), es, rtol=3e-6, atol=1e-7)
+    np.testing.assert_allclose(db.cpu().numpy(), eb, rtol=3e-6, atol=6e-4)
+    np.testing.assert_allclose(dl.cpu().numpy(), el, rtol=1e-6, atol=1e-4)
+    got_s = ds.cpu().numpy()
+    for i in range(n):
+        idx = np.nonzero(got_s[i] > np.float32(thr))[0]      # the kernel's own scores: no threshold ambiguity
+        k = int(cc[i].item())
+        assert k == len(idx) and k > 1000
+        assert np.array_equal(cp[i, :k].cpu().numpy(), idx)
+        assert np.array_equal(cs[i, :k].cpu().numpy(), got_s[i, idx])
+        assert np.array_equal(cb[i, :k].cpu().numpy(), db.cpu().numpy()[i, idx])
+        assert np.array_equal(cl[i, :k].cpu().numpy(), dl.cpu().numpy()[i, idx])
+    from face_crop_plus_amd.retinaface import nms_select
+    out = nms_select(cs, cb, cc, 0.4, "all")
+    torch.cuda.synchronize()
+    for i in range(n):
+        k = int(cc[i].item())
+        keep = R.nms_single(cb[i, :k].cpu().numpy(), cs[i, :k].cpu().numpy(), 0.4)
+        kc = int(out["keep_count"][i].item())
+        assert kc == len(keep)
+        assert out["keep_pos"][i, :kc].cpu().tolist() == keep
+
+
 def _run_nms(scores, boxes, thr, strategy, device, vis=0.6):
     """scores (n,P), boxes (n,P,4): threshold+compact on host (exactly like the mask gather), NMS on device."""
     from face_crop_plus_amd.retinaface import nms_select
