@@ -38,7 +38,8 @@ constexpr int IWB = (2 * SW + 5) * 3;          // 213 bytes per image row of the
 constexpr int IPITCH = 216;                    // binary16 elements per staged image row
 constexpr int IN_ELEMS = (IH + 1) * IPITCH;    // 6048 halves = 12 096 B
 constexpr int NT = 512;                         // 8 waves: (row-tile group 0..3) x (column tile 0..1)
-constexpr int NLOAD = (IH * IWB + NT - 1) / NT;  // 12 bytes per thread
+constexpr int TPR = 18;                        // threads per patch row: 27 x 18 = 486 of the 512 fetch; 18 = 6 pixels x 3
+constexpr int NLOAD = (IWB + TPR - 1) / TPR;   // 12 bytes per thread: columns c0 + 18 j of its row
 constexpr int SPITCH = 68;                     // floats per staged stem pixel (64 + 4: conflict-free pooling)
 constexpr int KSTEPS = 11;                     // 22 chunks of 8 K values (7 rows x 3 chunks, +1 zero chunk)
 
@@ -95,35 +96,25 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
     wl[q] = __builtin_bit_cast(f16x8, src[64]);
   }
 
-  // pooling pass: a thread always handles the same 8 channels (item & 7 == tid & 7)
-  float bias8[8], ws8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bias8[e] = p.bias[(tid & 7) * 8 + e];
-    ws8[e] = p.wscale[(tid & 7) * 8 + e];
-  }
+  // pooling pass: thread = (channel pair tid & 31, pooled column tid >> 5): always the same two channels
+  const int pc2 = 2 * (tid & 31), pcol = tid >> 5;
+  const float ws2a = p.wscale[pc2], ws2b = p.wscale[pc2 + 1], bias2a = p.bias[pc2], bias2b = p.bias[pc2 + 1];
+  float ws1a = 0.f, ws1b = 0.f, b1a = 0.f, b1b = 0.f;
+  if constexpr (HAS_C1) { ws1a = p.ws1[pc2]; ws1b = p.ws1[pc2 + 1]; b1a = p.b1[pc2]; b1b = p.b1[pc2 + 1]; }
   // HAS_C1: waves 0..5 own one 32 x 32 tile of the 96 x 64 conv1 output each (row tile wave >> 1, filters (wave & 1) * 32 ..).
   // Its filter fragments — 2 channel slices x 2 k-halves x hi / lo, 8 KiB for the whole conv, L1-resident — are fetched per
   // patch (the stem's 22 fragments fill the register file).  K order and term order are those of conv_igemm_f16x3_dma
   // (slices ascending; per k-half al*bh, ah*bl, ah*bh): same bits.
   const int c1rt = wave >> 1, c1ct = wave & 1;
 
-  // this thread's share of the image patch: byte index b -> (row, byte column)
-  int lrow[NLOAD], lcol[NLOAD];
-#pragma unroll
-  for (int i = 0; i < NLOAD; ++i) {
-    const int b = tid + NT * i;
-    lrow[i] = b / IWB;
-    lcol[i] = b - lrow[i] * IWB;
-  }
-  // Per byte of this thread's share: LDS element offset, pixel column inside the patch, channel mean.
-  int lxc[NLOAD], lmean[NLOAD], loff[NLOAD];
-#pragma unroll
-  for (int i = 0; i < NLOAD; ++i) {
-    lxc[i] = lcol[i] / 3;
-    lmean[i] = p.mean[lcol[i] - lxc[i] * 3];
-    loff[i] = lrow[i] < IH ? lrow[i] * IPITCH + lcol[i] : -1;
-  }
+  // this thread's share of the image patch: bytes c0 + 18 * j (j = 0 .. 11) of patch row tid / 18.  18 is a whole number
+  // of pixels, so the channel (and its mean), the row and its clamp are per thread, the pixel column advances by 6 per
+  // byte and the LDS offsets are immediates: four registers of bookkeeping and ~5 vector instructions per byte each for
+  // the fetch and the commit (a flat byte index took 48 registers and three times the arithmetic).
+  const int frow = tid / TPR, fc0 = tid - frow * TPR;          // rows >= IH (threads 486 ..) fetch nothing
+  const int fx0 = fc0 / 3, fch = fc0 - fx0 * 3;
+  const int fmean = fch == 0 ? p.mean[0] : (fch == 1 ? p.mean[1] : p.mean[2]);
+  _Float16* const fdst = inh + min(frow, IH - 1) * IPITCH + fc0;
   // fetch(): branch-free byte loads from clamped (always valid) addresses, nothing consumed before commit(), so
   // all of them are in flight under the MFMAs of the current patch
   uint8_t pre[NLOAD];
@@ -133,22 +124,24 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
     const int pyi = (patch / p.tiles_x) % p.tiles_y;
     const int ni = patch / (p.tiles_x * p.tiles_y);
     const int iy0 = 4 * pyi * PH - 5, ix0 = 4 * pxi * PW - 5;
-    const uint8_t* base = p.img + (long)ni * p.h * p.w * 3;
+    const int y = iy0 + frow;
+    const bool rowok = (unsigned)y < (unsigned)p.h && frow < IH;
+    const int yc = min(max(y, 0), p.h - 1);
+    const uint8_t* base = p.img + ((long)ni * p.h + yc) * p.w * 3 + fch;
     pre_ok = 0u;
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      const int y = iy0 + lrow[i], x = ix0 + lxc[i];
-      const bool ok = (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
-      pre_ok |= ok ? (1u << i) : 0u;
-      const int yc = min(max(y, 0), p.h - 1), xc = min(max(x, 0), p.w - 1);
-      pre[i] = base[(unsigned)((yc * p.w + xc) * 3 + (lcol[i] - lxc[i] * 3))];
+    for (int j = 0; j < NLOAD; ++j) {
+      const int x = ix0 + fx0 + 6 * j;
+      pre_ok |= (rowok && (unsigned)x < (unsigned)p.w) ? (1u << j) : 0u;
+      pre[j] = base[(unsigned)(min(max(x, 0), p.w - 1) * 3)];
     }
   };
   auto commit = [&]() {
+    if (frow < IH) {
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i)
-      if (loff[i] >= 0)     // x - mean, or 0 outside the image (the conv's zero padding)
-        inh[loff[i]] = (_Float16)(float)(((pre_ok >> i) & 1u) ? (int)pre[i] - lmean[i] : 0);
+      for (int j = 0; j < NLOAD; ++j)       // x - mean, or 0 outside the image (the conv's zero padding)
+        if (fc0 + TPR * j < IWB) fdst[TPR * j] = (_Float16)(float)(((pre_ok >> j) & 1u) ? (int)pre[j] - fmean : 0);
+    }
   };
 
   // zero the spare row / pitch padding once (read by the zero-weight K chunk: must be finite)
@@ -165,19 +158,31 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
     abase_t[k] = (2 * si) * IPITCH + 6 * sj;
   }
 
+#ifdef FCP_STEM_PROBE   // cycle attribution of the patch loop (experiment builds): workgroup 0, lane 0 of each wave
+  unsigned long long pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+  int npatch_done = 0;
+#define SPROBE(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); pc[k] += t_ - pt; pt = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SPROBE(k) do { } while (0)
+#endif
   int patch = blockIdx.x;
   if (patch < p.npatches) fetch(patch);
   for (; patch < p.npatches; patch += gridDim.x) {
+    SPROBE(8);
     commit();
+    SPROBE(0);
     lds_barrier();                                      // image patch visible
+    SPROBE(1);
     const int next = patch + gridDim.x;
     if (next < p.npatches) fetch(next);                 // global loads of the next patch fly under the MFMAs
+    SPROBE(2);
 
     const int pxi = patch % p.tiles_x;
     const int pyi = (patch / p.tiles_x) % p.tiles_y;
     const int ni = patch / (p.tiles_x * p.tiles_y);
     const int py0 = pyi * PH, px0 = pxi * PW;
     const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
+    const bool interior = sy0 >= 0 && sy0 + SH <= p.hs && sx0 >= 0 && sx0 + SW <= p.ws;   // workgroup-uniform
 
 #pragma unroll
     for (int k = 0; k < (NTILES + 3) / 4; ++k) {
@@ -187,71 +192,117 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-      for (int q = 0; q < KSTEPS; ++q) {
-        const int ch = 2 * q + half;                     // K chunk of this lane: filter row ch / 3, part ch % 3
+      // K chunk of this lane in step q: filter row ch / 3, part ch % 3 with ch = 2 * q + half; 8 consecutive K values = 8
+      // consecutive binary16 of one staged image row (4-byte aligned).  The fragment of step q + 1 is requested before the
+      // MFMAs of step q.
+      auto afrag = [&](int q) {
+        const int ch = 2 * q + half;
         const int kh = ch / 3, part = ch - kh * 3;
-        // 8 consecutive K values = 8 consecutive binary16 of one staged image row (4-byte aligned)
         const uint32_t* wp = reinterpret_cast<const uint32_t*>(inh + abase + kh * IPITCH + 8 * part);
         const u32x4_t raw = {wp[0], wp[1], wp[2], wp[3]};
-        const f16x8 a = __builtin_bit_cast(f16x8, raw);
+        return __builtin_bit_cast(f16x8, raw);
+      };
+      f16x8 a = afrag(0);
+#pragma unroll
+      for (int q = 0; q < KSTEPS; ++q) {
+        f16x8 an = a;
+        if (q + 1 < KSTEPS) an = afrag(q + 1);
+        __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, wl[q], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, wh[q], acc, 0, 0, 0);
+        a = an;
       }
       // raw accumulators -> stage.  Scale (> 0), bias and ReLU are monotone per channel, so they commute with the
-      // max and are applied to the pooled pixels instead of the stem pixels
+      // max and are applied to the pooled pixels instead of the stem pixels.  Stem pixels outside the stem map are the
+      // pool's padding: they are staged as -inf (border patches only), so the pooling pass reads unconditionally.
+      if (interior) {
+        if (t < NTILES - 1) {
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int row = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-        if (row < NSTEM) stage[row * SPITCH + ct * 32 + (lane & 31)] = acc[rr];
-      }
-    }
-    lds_barrier();                                      // stem tile staged; image patch no longer read
-
-    // max-pool 3x3 / 2 from LDS, 8 channels per item
-    for (int item = tid; item < PH * PW * 8; item += NT) {
-      const int c8 = (item & 7) * 8, pp = item >> 3;
-      const int py = pp / PW, px = pp - py * PW;
-      const int oy = py0 + py, ox = px0 + px;
-      if (oy >= p.hp || ox >= p.wp) continue;
-      float m[8];
+          for (int rr = 0; rr < 16; ++rr) {
+            const int row = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+            stage[row * SPITCH + ct * 32 + (lane & 31)] = acc[rr];
+          }
+        } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          // stem pixels outside the stem map are the pool's (-inf) padding
-          if ((unsigned)(sy0 + 2 * py + dy) >= (unsigned)p.hs || (unsigned)(sx0 + 2 * px + dx) >= (unsigned)p.ws) continue;
-          const float* s = stage + ((2 * py + dy) * SW + 2 * px + dx) * SPITCH + c8;
-          const f32x4 u = *reinterpret_cast<const f32x4*>(s), v = *reinterpret_cast<const f32x4*>(s + 4);
-          m[0] = fmaxf(m[0], u[0]); m[1] = fmaxf(m[1], u[1]); m[2] = fmaxf(m[2], u[2]); m[3] = fmaxf(m[3], u[3]);
-          m[4] = fmaxf(m[4], v[0]); m[5] = fmaxf(m[5], v[1]); m[6] = fmaxf(m[6], v[2]); m[7] = fmaxf(m[7], v[3]);
-        }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float v = m[e] * ws8[e] + bias8[e];
-        m[e] = v > 0.f ? v : 0.f;
-      }
-      const long pixel = ((long)ni * p.hp + oy) * p.wp + ox;
-      if (p.out_fmt == 1) {
-        u32x4_t hi, lo;
-        split8(f32x4{m[0], m[1], m[2], m[3]}, f32x4{m[4], m[5], m[6], m[7]}, hi, lo);
-        char* ob = reinterpret_cast<char*>(p.out) + pixel * p.out_ld * 4 + split_chan_off(c8);
-        *reinterpret_cast<u32x4_t*>(ob) = hi;
-        *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
-        if constexpr (HAS_C1) {                           // the same hi / lo bytes are conv1's operand: row pp, slice c8 / 32
-          const int q = (c8 & 31) >> 3, sw = swz1(pp);
-          char* trow = c1in + pp * 256 + (c8 >> 5) * 128;
-          *reinterpret_cast<u32x4_t*>(trow + ((q ^ sw) << 4)) = hi;
-          *reinterpret_cast<u32x4_t*>(trow + (((4 + q) ^ sw) << 4)) = lo;
+          for (int rr = 0; rr < 16; ++rr) {
+            const int row = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+            if (row < NSTEM) stage[row * SPITCH + ct * 32 + (lane & 31)] = acc[rr];
+          }
         }
       } else {
-        float* dst = p.out + pixel * p.out_ld + c8;
-        *reinterpret_cast<f32x4*>(dst) = f32x4{m[0], m[1], m[2], m[3]};
-        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{m[4], m[5], m[6], m[7]};
+        int hv = half;                                  // opaque: the (si, sj) of 48 rows must not be hoisted out of the patch loop
+        asm volatile("" : "+v"(hv));
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int row = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hv;
+          const int si = row / SW, sj = row - si * SW;
+          const bool in = (unsigned)(sy0 + si) < (unsigned)p.hs && (unsigned)(sx0 + sj) < (unsigned)p.ws;
+          if (row < NSTEM) stage[row * SPITCH + ct * 32 + (lane & 31)] = in ? acc[rr] : -INFINITY;
+        }
       }
     }
+    SPROBE(3);
+    lds_barrier();                                      // stem tile staged; image patch no longer read
+    SPROBE(4);
+
+    // HAS_C1: conv1's filter fragments (8 x 16 B per lane, L1-resident) are requested here, a pooling pass ahead of use
+    f16x8 c1w[8];
+    if constexpr (HAS_C1) {
+      if (c1rt < 3) {
+        const char* wrow = p.w1 + (size_t)(c1ct * 32 + (lane & 31)) * 256;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+          for (int sh = 0; sh < 2; ++sh) {
+            c1w[(sl * 2 + sh) * 2] = *reinterpret_cast<const f16x8*>(wrow + sl * 128 + (2 * sh + half) * 16);
+            c1w[(sl * 2 + sh) * 2 + 1] = *reinterpret_cast<const f16x8*>(wrow + sl * 128 + (4 + 2 * sh + half) * 16);
+          }
+      }
+    }
+    // max-pool 3x3 / 2 from LDS, separable: a thread owns two channels of one pooled column (5 pooled pixels): the
+    // horizontal maxima of the 11 staged rows (33 8-byte reads, unconditional), then the vertical ones — 32 three-input
+    // maxima for 10 outputs, one round on all eight waves.
+    {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const float* sp = stage + (2 * pcol) * SPITCH + pc2;
+      f32x2 rm[SH];
+#pragma unroll
+      for (int si = 0; si < SH; ++si) {
+        const f32x2 a = *reinterpret_cast<const f32x2*>(sp + (si * SW) * SPITCH);
+        const f32x2 b = *reinterpret_cast<const f32x2*>(sp + (si * SW + 1) * SPITCH);
+        const f32x2 c = *reinterpret_cast<const f32x2*>(sp + (si * SW + 2) * SPITCH);
+        rm[si][0] = fmaxf(fmaxf(a[0], b[0]), c[0]);
+        rm[si][1] = fmaxf(fmaxf(a[1], b[1]), c[1]);
+      }
+      const int ox = px0 + pcol;
+#pragma unroll
+      for (int py = 0; py < PH; ++py) {
+        const int oy = py0 + py;
+        if (oy >= p.hp || ox >= p.wp) continue;
+        float v0 = fmaxf(fmaxf(rm[2 * py][0], rm[2 * py + 1][0]), rm[2 * py + 2][0]) * ws2a + bias2a;
+        float v1 = fmaxf(fmaxf(rm[2 * py][1], rm[2 * py + 1][1]), rm[2 * py + 2][1]) * ws2b + bias2b;
+        v0 = v0 > 0.f ? v0 : 0.f;
+        v1 = v1 > 0.f ? v1 : 0.f;
+        const long pixel = ((long)ni * p.hp + oy) * p.wp + ox;
+        if (p.out_fmt == 1) {
+          const unsigned hu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));   // split8's arithmetic
+          const unsigned lu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fcp_mix_diff<0>(v0, hu), fcp_mix_diff<1>(v1, hu)));
+          char* ob = reinterpret_cast<char*>(p.out) + pixel * p.out_ld * 4 + split_chan_off(pc2);
+          *reinterpret_cast<unsigned*>(ob) = hu;
+          *reinterpret_cast<unsigned*>(ob + 64) = lu;
+          if constexpr (HAS_C1) {                         // the same hi / lo bytes are conv1's operand: row pp, slice pc2 / 32
+            const int pp = py * PW + pcol;
+            const int q = (pc2 & 31) >> 3, sw = swz1(pp);
+            char* trow = c1in + pp * 256 + (pc2 >> 5) * 128 + (pc2 & 7) * 2;
+            *reinterpret_cast<unsigned*>(trow + ((q ^ sw) << 4)) = hu;
+            *reinterpret_cast<unsigned*>(trow + (((4 + q) ^ sw) << 4)) = lu;
+          }
+        } else {
+          *reinterpret_cast<f32x2*>(p.out + pixel * p.out_ld + pc2) = f32x2{v0, v1};
+        }
+      }
+    }
+    SPROBE(5);
     if constexpr (HAS_C1) {
       lds_barrier();                                    // conv1 operand complete; the stem stage is no longer read
       if (c1rt < 3) {
@@ -260,13 +311,11 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         const int row = c1rt * 32 + (lane & 31), sw = swz1(row);
         const char* arow = c1in + row * 256;
-        const char* wrow = p.w1 + (size_t)(c1ct * 32 + (lane & 31)) * 256;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
           for (int sh = 0; sh < 2; ++sh) {
-            const f16x8 bh = *reinterpret_cast<const f16x8*>(wrow + sl * 128 + (2 * sh + half) * 16);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(wrow + sl * 128 + (4 + 2 * sh + half) * 16);
+            const f16x8 bh = c1w[(sl * 2 + sh) * 2], bl = c1w[(sl * 2 + sh) * 2 + 1];
             const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + sl * 128 + (((2 * sh + half) ^ sw) << 4));
             const f16x8 al = *reinterpret_cast<const f16x8*>(arow + sl * 128 + (((4 + 2 * sh + half) ^ sw) << 4));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
@@ -280,30 +329,41 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
         }
       }
       lds_barrier();                                    // conv1's fp32 tile staged
-      for (int item = tid; item < PH * PW * 8; item += NT) {
-        const int c8 = (item & 7) * 8, pp = item >> 3;
-        const int py = pp / PW, px = pp - py * PW;
-        const int oy = py0 + py, ox = px0 + px;
-        if (oy >= p.hp || ox >= p.wp) continue;
-        const float* cs = stage + pp * CPITCH + c8;
-        const f32x4 u = *reinterpret_cast<const f32x4*>(cs), v = *reinterpret_cast<const f32x4*>(cs + 4);
-        float t[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+      {                                                 // thread = (channel pair, pooled column) like the pooling pass
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const int ox = px0 + pcol;
+        f32x2 cv[PH];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {                   // the generic epilogue's expressions (act_slope 0, alpha 1)
-          float x = t[e] * p.ws1[c8 + e] + p.b1[c8 + e];
-          x = x >= 0.f ? x : x * 0.f;
-          t[e] = x * 1.f;
+        for (int py = 0; py < PH; ++py) cv[py] = *reinterpret_cast<const f32x2*>(stage + (py * PW + pcol) * CPITCH + pc2);
+#pragma unroll
+        for (int py = 0; py < PH; ++py) {
+          const int oy = py0 + py;
+          if (oy >= p.hp || ox >= p.wp) continue;
+          float x0 = cv[py][0] * ws1a + b1a, x1 = cv[py][1] * ws1b + b1b;   // the generic epilogue's expressions (act_slope 0, alpha 1)
+          x0 = x0 >= 0.f ? x0 : x0 * 0.f;
+          x1 = x1 >= 0.f ? x1 : x1 * 0.f;
+          x0 = x0 * 1.f; x1 = x1 * 1.f;
+          const unsigned hu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+          const unsigned lu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fcp_mix_diff<0>(x0, hu), fcp_mix_diff<1>(x1, hu)));
+          const long pixel = ((long)ni * p.hp + oy) * p.wp + ox;
+          char* ob = reinterpret_cast<char*>(p.t1) + pixel * p.t1_ld * 4 + split_chan_off(pc2);
+          *reinterpret_cast<unsigned*>(ob) = hu;
+          *reinterpret_cast<unsigned*>(ob + 64) = lu;
         }
-        u32x4_t hi, lo;
-        split8(f32x4{t[0], t[1], t[2], t[3]}, f32x4{t[4], t[5], t[6], t[7]}, hi, lo);
-        const long pixel = ((long)ni * p.hp + oy) * p.wp + ox;
-        char* ob = reinterpret_cast<char*>(p.t1) + pixel * p.t1_ld * 4 + split_chan_off(c8);
-        *reinterpret_cast<u32x4_t*>(ob) = hi;
-        *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
       }
     }
+    SPROBE(6);
     lds_barrier();                                      // stage free for the next patch
+    SPROBE(7);
+#ifdef FCP_STEM_PROBE
+    ++npatch_done;
+#endif
   }
+#ifdef FCP_STEM_PROBE
+  if (blockIdx.x == 0 && lane == 0)
+    printf("wave %d: %d patches; commit %llu, barrier %llu, fetch issue %llu, MFMAs + stage %llu, barrier %llu, pool + stores %llu, conv1 %llu, barrier %llu, loop %llu\n",
+           wave, npatch_done, pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], pc[6], pc[7], pc[8]);
+#endif
 }
 
 }  // namespace
