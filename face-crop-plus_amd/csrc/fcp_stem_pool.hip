@@ -11,15 +11,24 @@
 //
 // Mapping.  A persistent workgroup of 8 waves (two per SIMD) walks patches of 5 x 16 pooled pixels.  A patch
 // needs 11 x 33 stem pixels (12 MFMA row tiles of 32) from a 27 x 71 pixel image patch.  The patch is fetched as
-// bytes (branch-free, clamped addresses, one patch ahead so the loads fly under the MFMAs), converted ONCE to
-// binary16 (x - mean; 0 outside the image = the conv's zero padding) and staged in LDS.  K = 7 filter rows x 24
-// (21 = 7 taps x 3 channels, padded): a lane's 8 consecutive K values are 8 consecutive binary16 of one staged
-// row, i.e. the MFMA fragment is four aligned dword reads with no arithmetic.  Wave w owns column tile w & 1
-// (32 filters; its 22 fragments = 11 k-steps x hi / lo stay in registers for the whole kernel) and the row tiles
-// (w >> 1) + 4k.  Raw accumulators go to LDS as fp32; the 3 x 3 / 2 max is taken there over the pixels inside the
-// stem map and scale, bias and ReLU — monotone per channel, so they commute with the max — are applied to the
-// 80 pooled pixels only, which leave as 16-byte stores.  Barriers order LDS traffic only (s_waitcnt lgkmcnt(0) +
+// bytes (branch-free, clamped addresses, one patch ahead so the loads fly under the MFMAs; a thread owns 12 bytes of
+// ONE patch row, 18 bytes = 6 pixels apart, so its row clamp, channel and mean are fixed and the LDS offsets are
+// immediates), converted ONCE to binary16 (x - mean; 0 outside the image = the conv's zero padding) and staged in LDS.
+// K = 7 filter rows x 24 (21 = 7 taps x 3 channels, padded): a lane's 8 consecutive K values are 8 consecutive
+// binary16 of one staged row, i.e. the MFMA fragment is four aligned dword reads with no arithmetic, requested one
+// k-step ahead of the MFMAs that use it.  Wave w owns column tile w & 1 (32 filters; its 22 fragments = 11 k-steps x
+// hi / lo stay in registers for the whole kernel) and the row tiles (w >> 1) + 4k.  Raw accumulators go to LDS as fp32
+// (-inf for stem pixels outside the stem map: border patches only); the 3 x 3 / 2 max is taken there separably — a
+// thread owns two channels of one pooled column: 33 unconditional 8-byte reads, 11 horizontal and 5 vertical three-way
+// maxima for 10 outputs, one round on all 512 threads — and scale, bias and ReLU — monotone per channel, so they commute
+// with the max — are applied to the 80 pooled pixels only.  Barriers order LDS traffic only (s_waitcnt lgkmcnt(0) +
 // s_barrier): neither the output stores nor the prefetch are drained at a barrier.
+//
+// Where the time goes (tools/stem_probe.sh / stem_ablate.sh, cycles per patch and wave at batch 64, 640^2): MFMAs +
+// staging 5700-6400 (4224 is the matrix pipe's share; the 48 staging writes per wave cost ~1900 of it, the fragment
+// reads ~1100), pooling + stores 2100-2600, byte fetch 1000-2000 (96 byte-load instructions per patch on the vector
+// memory path), commit 1300.  Unaligned dword loads instead of bytes were slower (3 per thread cost more than 12 byte
+// loads), recomputing the fetch bookkeeping per patch cost 3x its registers' worth in vector instructions.
 #include "fcp_conv_common.h"
 
 using namespace fcp_conv;
@@ -202,6 +211,10 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
         const u32x4_t raw = {wp[0], wp[1], wp[2], wp[3]};
         return __builtin_bit_cast(f16x8, raw);
       };
+#ifdef FCP_STEM_ABLATE_AREAD   // experiment: no A-fragment LDS reads (wrong results)
+      auto afrag2 = [&](int q) { return wh[q]; };
+#define afrag afrag2
+#endif
       f16x8 a = afrag(0);
 #pragma unroll
       for (int q = 0; q < KSTEPS; ++q) {
@@ -212,6 +225,13 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, wh[q], acc, 0, 0, 0);
         a = an;
       }
+#ifdef FCP_STEM_ABLATE_AREAD
+#undef afrag
+#endif
+#ifdef FCP_STEM_ABLATE_STAGE  // experiment: one staged value per tile instead of 16 (wrong results)
+      if (acc[0] + acc[5] + acc[10] + acc[15] == 12345.f) stage[tid] = acc[3];
+      continue;
+#endif
       // raw accumulators -> stage.  Scale (> 0), bias and ReLU are monotone per channel, so they commute with the
       // max and are applied to the pooled pixels instead of the stem pixels.  Stem pixels outside the stem map are the
       // pool's padding: they are staged as -inf (border patches only), so the pooling pass reads unconditionally.
