@@ -221,8 +221,8 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
         f16x8 an = a;
         if (q + 1 < KSTEPS) an = afrag(q + 1);
         __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, wl[q], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, wh[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[q], a, acc, 0, 0, 0);     // filters as the row operand: see below
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q], a, acc, 0, 0, 0);
         a = an;
       }
 #ifdef FCP_STEM_ABLATE_AREAD
@@ -232,32 +232,24 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
       if (acc[0] + acc[5] + acc[10] + acc[15] == 12345.f) stage[tid] = acc[3];
       continue;
 #endif
-      // raw accumulators -> stage.  Scale (> 0), bias and ReLU are monotone per channel, so they commute with the
-      // max and are applied to the pooled pixels instead of the stem pixels.  Stem pixels outside the stem map are the
-      // pool's padding: they are staged as -inf (border patches only), so the pooling pass reads unconditionally.
-      if (interior) {
-        if (t < NTILES - 1) {
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr) {
-            const int row = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-            stage[row * SPITCH + ct * 32 + (lane & 31)] = acc[rr];
-          }
-        } else {
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr) {
-            const int row = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-            if (row < NSTEM) stage[row * SPITCH + ct * 32 + (lane & 31)] = acc[rr];
-          }
-        }
-      } else {
-        int hv = half;                                  // opaque: the (si, sj) of 48 rows must not be hoisted out of the patch loop
-        asm volatile("" : "+v"(hv));
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const int row = t * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hv;
+      // raw accumulators -> stage.  The tile was computed transposed (filters x pixels): a lane holds ONE stem pixel
+      // (lane & 31) and filters 8 g + 4 half + 0..3 of its column tile, i.e. four 16-byte staging writes per tile instead
+      // of sixteen 4-byte ones, one validity test per lane.  Scale (> 0), bias and ReLU are monotone per channel, so they
+      // commute with the max and are applied to the pooled pixels instead of the stem pixels.  Stem pixels outside the
+      // stem map are the pool's padding: they are staged as -inf, so the pooling pass reads unconditionally.
+      {
+        const int row = t * 32 + (lane & 31);
+        bool in = true;
+        if (!interior) {
           const int si = row / SW, sj = row - si * SW;
-          const bool in = (unsigned)(sy0 + si) < (unsigned)p.hs && (unsigned)(sx0 + sj) < (unsigned)p.ws;
-          if (row < NSTEM) stage[row * SPITCH + ct * 32 + (lane & 31)] = in ? acc[rr] : -INFINITY;
+          in = (unsigned)(sy0 + si) < (unsigned)p.hs && (unsigned)(sx0 + sj) < (unsigned)p.ws;
+        }
+        if (row < NSTEM) {
+          float* dst = stage + row * SPITCH + ct * 32 + 4 * half;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(dst + 8 * g) = in ? f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}
+                                                        : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         }
       }
     }
@@ -338,15 +330,14 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
             const f16x8 bh = c1w[(sl * 2 + sh) * 2], bl = c1w[(sl * 2 + sh) * 2 + 1];
             const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + sl * 128 + (((2 * sh + half) ^ sw) << 4));
             const f16x8 al = *reinterpret_cast<const f16x8*>(arow + sl * 128 + (((4 + 2 * sh + half) ^ sw) << 4));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc, 0, 0, 0);   // transposed tile (filters x pixels), same
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc, 0, 0, 0);   // products and K order: 16-byte staging writes
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc, 0, 0, 0);
           }
+        float* dst = stage + row * CPITCH + c1ct * 32 + 4 * half;
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const int r = c1rt * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-          stage[r * CPITCH + c1ct * 32 + (lane & 31)] = acc[rr];
-        }
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(dst + 8 * g) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
       }
       lds_barrier();                                    // conv1's fp32 tile staged
       {                                                 // thread = (channel pair, pooled column) like the pooling pass
