@@ -72,6 +72,8 @@ def parse():
                     help="HIP streams the detector splits a batch over (product default 2; 1 = single stream, conv "
                          "launches then timed inside the timed region)")
     ap.add_argument("--roofline-steps", type=int, default=3, help="single-stream passes the conv launches are timed in")
+    ap.add_argument("--launch-table", default=None, metavar="CSV",
+                    help="write the per-launch table of the roofline passes (label, us, TFLOP/s, algorithmic GB/s) to this file")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
 
@@ -263,7 +265,10 @@ def _pmc_traffic(key):
         return round(json.load(f)["hbm_bytes_per_launch"]), "profiles/" + prof[-1]
 
 
-def conv_roofline(p: Pipeline, nsteps, live, timed_ms=None, traffic_key=None):
+LAUNCH_TABLE = None                 # --launch-table: CSV path for the per-launch table of the headline workload's roofline passes
+
+
+def conv_roofline(p: Pipeline, nsteps, live, timed_ms=None, traffic_key=None, table=False):
     """Roofline record of the conv engine from per-launch HIP events on the launch stream: the events of the timed
     steps (`live`, single-stream runs) or of `nsteps` extra single-stream passes right after the timed region.
     `timed_ms`: ms per step of the timed region (the product configuration, possibly two detector streams): the record
@@ -286,8 +291,17 @@ def conv_roofline(p: Pipeline, nsteps, live, timed_ms=None, traffic_key=None):
         torch.cuda.synchronize()
         p.det.streams, p.graphed = saved, graphed
     timing, E.ConvStats.timing = E.ConvStats.timing, None
-    conv_ms = sum(a.elapsed_time(b) for a, b, _ in timing) / nsteps
-    conv_flops = sum(f for _, _, f in timing) / nsteps
+    if LAUNCH_TABLE and timed_ms is not None and table:
+        import csv
+        per = len(timing) // nsteps
+        with open(LAUNCH_TABLE, "w", newline="") as f:
+            wr = csv.writer(f)
+            wr.writerow(["launch", "us", "algorithmic_tflops", "algorithmic_gb_per_s"])
+            for i in range(per):
+                us = sum(timing[i + s_ * per][0].elapsed_time(timing[i + s_ * per][1]) for s_ in range(nsteps)) / nsteps * 1e3
+                wr.writerow([timing[i][3], round(us, 1), round(timing[i][2] / us / 1e6, 1), round(timing[i][4] / us / 1e3, 1)])
+    conv_ms = sum(t[0].elapsed_time(t[1]) for t in timing) / nsteps
+    conv_flops = sum(t[2] for t in timing) / nsteps
     launches = len(timing) // nsteps
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
     split = p.precision == "f16x3"
@@ -452,6 +466,8 @@ def run_extra(dev, sds, args):
 
 def main():
     args = parse()
+    global LAUNCH_TABLE
+    LAUNCH_TABLE = args.launch_table
     full = args.workload == "full"
     if args.batch is None:
         args.batch = 32 if full else 64
@@ -500,7 +516,7 @@ def main():
         std = not full and args.batch == 64 and args.size == 640
         key = ("f16x3_pmc_conv" if args.precision == "f16x3" else "f32_pmc_conv") if std else None
         roofline = conv_roofline(p, args.steps if live else args.roofline_steps, live,
-                                 timed_ms=elapsed / args.steps * 1e3, traffic_key=key)
+                                 timed_ms=elapsed / args.steps * 1e3, traffic_key=key, table=True)
         if not args.graph:
             hbm_kernels = hbm_kernel_records(p)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

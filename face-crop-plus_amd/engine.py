@@ -261,7 +261,7 @@ class ConvStats:
     enabled = False
     flops = 0
     launches = 0
-    timing = None  # list of (start_event, end_event, flops) when per-launch timing is on
+    timing = None  # list of (start_event, end_event, flops, label, algorithmic bytes) when per-launch timing is on
 
     @classmethod
     def reset(cls):
@@ -379,7 +379,12 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
         N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
     if timing is not None:
         e1.record()
-        timing.append((e0, e1, pc.flops_per_pixel * m))
+        byts = 4 * (m * (pc.cout + (pc.cout if res1 is not None else 0) + (pc.cout if res2 is not None else 0))
+                    + x.n * in_h * in_w * x.c // (4 if in_up2 else 1) + (m * x2.c if x2 is not None else 0)
+                    + pc.cout * pc.cin * pc.kh * pc.kw)
+        timing.append((e0, e1, pc.flops_per_pixel * m,
+                       f"conv {pc.kh}x{pc.kw} s{pc.stride} {pc.cin}->{pc.cout} @{oh}x{ow} tile {d.tile_m}x{d.tile_n}"
+                       f"{' bal' if d.flags & N.CONV_BALANCE_TAIL else ''}{' +res' if res1 is not None else ''}", byts))
     if ConvStats.enabled:
         ConvStats.flops += pc.flops_per_pixel * m
         ConvStats.launches += 1
@@ -450,7 +455,10 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
         N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
     if timing is not None:
         e1.record()
-        timing.append((e0, e1, flops))
+        c, nout, cn = pc3.cin, pc3.cout, pc1n.cout
+        byts = 4 * (m * (c + nout + (nout if res is not None else 0) + cn) + (0 if pc2 is None else 9 * c * c) + c * nout + nout * cn)
+        timing.append((e0, e1, flops, f"chain {'3x3 ' if pc2 is not None else ''}{c}->{nout}->{cn} @{t1.h}x{t1.w}"
+                       f"{' +res' if res is not None else ''}", byts))
     if ConvStats.enabled:
         ConvStats.flops += flops
         ConvStats.launches += 1
@@ -551,7 +559,8 @@ def stem_relu_pool_u8(ps: PackedStem, images_u8: torch.Tensor, out: Act | None =
                 "fcp_stem7x7s2_relu_pool_u8")
     if timing is not None:
         e1.record()
-        timing.append((e0, e1, flops))
+        byts = n * h * w * 3 + 4 * n * hp * wp * 64 * (2 if conv1 is not None else 1)
+        timing.append((e0, e1, flops, f"stem 7x7 s2 + pool{' + conv1' if conv1 is not None else ''} @{hp}x{wp}", byts))
     if ConvStats.enabled:
         ConvStats.flops += flops
         ConvStats.launches += 1
