@@ -266,12 +266,20 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   FCP_REQUIRE(d->n > 0 && d->in_h > 0 && d->in_w > 0 && d->cout > 0, "conv: bad sizes");
   const bool big = d->tile_m == 256, halo = d->tile_m == 1;
   FCP_REQUIRE(d->tile_m == 0 || d->tile_m == 128 || big || halo, "conv: tile_m must be 0/128/256 (or 1: halo-tile 3x3)");
+  const bool halo_wide = halo && d->tile_n != 32;      // tile_n 64 / 128: column tiles inner, filters through a tap ring
   if (halo)
     FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && !d->in_up2 && d->kh == 3 && d->kw == 3 && d->stride == 1 &&
                 d->pad == 1 && d->cout <= 64 && d->cout % 8 == 0 && d->cin >= 64 && !d->in2 &&
-                (!d->res1 || (d->res1_h == d->out_h && d->res1_w == d->out_w)),
+                (!d->res1 || (d->res1_h == d->out_h && d->res1_w == d->out_w)) || halo_wide,
                 "conv: the halo-tile kernel needs a 3x3 / stride 1 / pad 1 conv with cin >= 64, cout <= 64 (cout %% 8 == 0) on the "
                 "fp16x3 path with a split32 input, no second source, no resized residual");
+  if (halo_wide)
+    FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && !d->in_up2 && d->kh == 3 && d->kw == 3 && d->stride == 1 &&
+                d->pad == 1 && d->cout % 8 == 0 && d->cin >= 64 && d->cin % 64 == 0 && !d->in2 &&
+                ((d->tile_n == 64 && d->cout <= 64 && (!d->res1 || (d->res1_h == d->out_h && d->res1_w == d->out_w))) ||
+                 (d->tile_n == 128 && d->cout <= 128 && !d->res1 && !d->res2)),
+                "conv: the wide halo-tile kernel (tile_m 1, tile_n 64 / 128) needs a 3x3 / stride 1 / pad 1 conv with cin %% 64 == 0, "
+                "cout <= tile_n (cout %% 8 == 0; no residuals above 64 filters) on the fp16x3 path with a split32 input");
   FCP_REQUIRE(d->tile_n == 32 || d->tile_n == 64 || d->tile_n == 128 || (big && (d->tile_n == 256 || d->tile_n == 192)),
               "conv: tile_n must be 32/64/128 (or 192 / 256 with tile_m 256)");
   if (big)
@@ -394,7 +402,7 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
                   "conv(halo): wscale / bias must be 16-byte aligned");
       k.in2_bytes = (unsigned)out_bytes;                // halo launches take no second source: the field carries |out|
       k.w_bytes = (unsigned)((unsigned long)fcp_cdiv(d->cout, 128) * 128ul * k.wrow * 4ul);
-      return launch_f16x3_halo(k, s);
+      return halo_wide ? launch_f16x3_halo_wide(k, s) : launch_f16x3_halo(k, s);
     }
     if (big) {
       k.w_bytes = (unsigned)((unsigned long)fcp_cdiv(d->cout, 128) * 128ul * k.wrow * 4ul);   // filters are padded to 128 rows

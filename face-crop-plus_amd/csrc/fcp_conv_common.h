@@ -419,7 +419,8 @@ __device__ __forceinline__ void conv_epilogue8(const ConvK& p, f32x16 (&acc)[TM]
 
 int launch_f16x3(const ConvK& k, int tile_n, bool cin4, hipStream_t s);
 int launch_f16x3_dma(const ConvK& k, int tile_n, int stages, hipStream_t s);
-int launch_f16x3_halo(const ConvK& k, hipStream_t s);           // 3x3 / stride 1 / pad 1, cout <= 32: 8x32 halo tiles
+int launch_f16x3_halo(const ConvK& k, hipStream_t s);           // 3x3 / stride 1 / pad 1, cout <= 64: 8x32 halo tiles, one pass per 32 filters
+int launch_f16x3_halo_wide(const ConvK& k, hipStream_t s);      // same patch, cout <= 128, cin % 64 == 0: column tiles inner, tap ring
 int launch_f16x3_big(const ConvK& k, int tile_n, hipStream_t s);   // 256-row tiles, tile_n 128 | 256
 
 }  // namespace fcp_conv

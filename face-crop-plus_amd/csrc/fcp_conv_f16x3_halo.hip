@@ -441,6 +441,389 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// "Wide" halo-tile kernel: 3x3 / stride 1 / pad 1 with 33 .. 128 filters (TN = 2 or 4 column tiles of 32), cin % 64 == 0.
+//
+// The kernel above runs one PASS per 32 filters over a staged halo patch and re-reads the pixel fragments from LDS in every
+// pass (one 16-byte read per MFMA).  Here a compute wave keeps its pixel fragments (2 row tiles x hi / lo) for a k-half
+// and walks the TN column tiles with them: 4 + 2 TN fragment reads per 6 TN MFMAs (0.5 per MFMA at TN = 4, the 256-row
+// kernel's ratio), and the operand DMA per MFMA stays the halo kernel's (one 44 KB patch per 32-channel slice for nine taps).
+// The filters of a slice (9 x TN x 4 KB = 147 KB at TN = 4) do not fit beside two halo stages, so they stream through a
+// ring of four TAP buffers (TN x 4 KB each; stream tap G lives in slot G % 4).  The stream is: tiles chained, slices
+// outer, taps inner.  Tap g's step starts with the ONE barrier of the tap and then reads tap g's own filter fragments
+// just in time (two in flight) plus the first fragments of tap g + 1; so behind barrier g the slot of tap g - 1 is dead
+// and the loader waves refill it with tap g + 3, which has two tap steps (96 MFMAs per wave at TN = 4) to land: a loader
+// arrives at barrier g + 1 when everything it issued BEFORE barrier g has landed (s_waitcnt vmcnt(n) with n = what it issued
+// behind barrier g).  A slice's halo stage dies with its tap 8 and takes the slice two ahead.  Eighteen taps = two slices =
+// one statically unrolled UNIT (cin % 64 == 0): taps, stages and ring slots are immediates (the four slot bases rotate by
+// two per unit).  Same arithmetic and K order as every other fp16x3 kernel (per accumulator and k-half: al*bh, ah*bl,
+// ah*bh; slices outer, taps inner) => bit-identical results.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TN, bool RES>   // RES: the epilogue supports the two residual inputs (registers: only instantiated for TN = 2)
+__global__ void __launch_bounds__(512, 1) conv3x3_halo_wide_f16x3(const ConvK p) {
+  constexpr int TAPB = TN * 32 * ROWB;                // filter bytes of one tap: TN x 32 rows x 128 B
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+  const int tiles_x = (p.out_w + TW - 1) / TW, tiles_y = (p.out_h + TH - 1) / TH;
+  const int ntiles = p.n * tiles_x * tiles_y;
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int per_x = (ntiles + 7) / 8;
+  const int xcd = bid & 7, slot = bid >> 3, slots = (nb + 7 - xcd) / 8;
+
+  const int lane = threadIdx.x & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool loader = wave8 >= 4;
+  const int wave_u = wave8 & 3;
+  const int tid = threadIdx.x & 255;
+  const int nslices = p.ctiles;                       // even (launcher)
+  const int T = 9 * nslices;                          // taps per tile
+
+  int it = slot;
+  if (it >= per_x || xcd * per_x + it >= ntiles) return;
+
+  if (loader) {
+    // =================================================================== loader waves
+    const int lrow = tid >> 3;
+    const int csrc = (tid & 7) ^ swz(lrow);
+    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    const unsigned wbase = (unsigned)((lrow * p.wrow) * 4 + csrc * 16);
+    unsigned abase[A_LD];
+    int hyx[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int hr = lrow + 32 * i;
+      const int hy = hr / HW_, hx = hr - hy * HW_;
+      hyx[i] = hr < (TH + 2) * HW_ ? (hy << 8 | hx) : -1;
+    }
+    auto tile_setup = [&](int tile) {
+      const int tx = tile % tiles_x;
+      const int ty = (tile / tiles_x) % tiles_y;
+      const int ni = tile / (tiles_x * tiles_y);
+      const int y0 = ty * TH, x0 = tx * TW;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        const int y = y0 - 1 + (hyx[i] >> 8), x = x0 - 1 + (hyx[i] & 255);
+        const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)p.in_h && (unsigned)x < (unsigned)p.in_w;
+        abase[i] = ok ? ((unsigned)((ni * p.in_h + y) * p.in_w + x) * (unsigned)p.in_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
+      }
+    };
+    constexpr int HALO_I = A_LD - 1;                      // halo instructions every loader wave issues (waves 0..2: one more)
+    auto dma_halo = [&](int cs, int stage) {
+      char* a = lds + stage * A_BYTES + wave_u * 8 * ROWB;
+#pragma unroll
+      for (int i = 0; i < A_LD - 1; ++i) {
+        const unsigned ro = abase[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * i * ROWB), 16,
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(cs * 128)), 0, 0, 0);
+      }
+      if (wave_u < 3) {
+        const unsigned ro = abase[A_LD - 1];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 32 * (A_LD - 1) * ROWB), 16,
+                                                 (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(cs * 128)), 0, 0, 0);
+      }
+    };
+    // within-tile tap gt (slice gt / 9, tap gt % 9) into ring slot `rs`: TN instructions (32 filter rows each)
+    auto dma_tap = [&](int gt, int rs) {
+      const int cs = gt / 9, tap = gt - cs * 9;
+      char* b = lds + B_OFF + rs * TAPB + wave_u * 8 * ROWB;
+      const unsigned wo = wbase + (unsigned)(cs * 9 * 128 + tap * 128);
+#pragma unroll
+      for (int k = 0; k < TN; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 32 * k * ROWB), 16,
+                                                 (int)(wo + (unsigned)(k * 32 * p.wrow * 4)), 0, 0, 0);
+    };
+
+    tile_setup(xcd * per_x + it);
+    dma_halo(0, 0);
+    dma_halo(1, 1);
+    dma_tap(0, 0); dma_tap(1, 1); dma_tap(2, 2);          // T >= 18
+    int g = 0;                                            // within-tile index of the tap whose barrier comes next
+    unsigned G = 0;                                       // the same, counted over the whole stream (ring slot = G % 4)
+    int pend = 0;                                         // instructions issued behind the previous barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // P: slices 0, 1 and taps 0, 1, 2 are in LDS
+    for (;;) {
+      const int nit = it + slots, ntile = xcd * per_x + nit;
+      const bool more = nit < per_x && ntile < ntiles;
+      // everything issued before the previous barrier has landed (what was issued behind it may still fly)
+      if (pend >= TN + HALO_I) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN + HALO_I) : "memory");
+      else if (pend >= TN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                  // barrier of tap g: the slot of tap g - 1 is dead
+      pend = 0;
+      const int t3 = g + 3;
+      if (t3 < T) { dma_tap(t3, (int)((G + 3u) & 3u)); pend += TN; }
+      else if (more) { dma_tap(t3 - T, (int)((G + 3u) & 3u)); pend += TN; }
+      if (g > 0 && g % 9 == 0) {                                     // tap g - 1 was tap 8 of slice g / 9 - 1: its stage takes the slice two ahead
+        const int died = g / 9 - 1, s2 = died + 2, stage = died & 1;
+        if (s2 < nslices) { dma_halo(s2, stage); pend += HALO_I; }
+        else if (more) {                                             // s2 == nslices: the next tile's first slice; its addresses replace this tile's
+          tile_setup(ntile);
+          dma_halo(0, stage);
+          pend += HALO_I;
+        }
+      }
+      ++g; ++G;
+      if (g == T) {
+        // the tile's last tap is running; its last slice lives in stage 1, which hosts the epilogue before it is refilled
+        __builtin_amdgcn_s_barrier();                                  // E: the compute waves have read the finished tile back from stage 1
+        if (!more) return;
+        dma_halo(1, 1);
+        pend += HALO_I;
+        it = nit;
+        g = 0;
+      }
+    }
+  }
+
+  // ===================================================================== compute waves
+  const int xl = lane & 31, half = lane >> 5;
+  // Fragment addresses of the halo patch (see the kernel above).  Recomputed at the top of every unit from an opaque copy
+  // of the lane index (~100 vector instructions per 864 MFMAs): kept across the epilogue they are what the register
+  // allocator spills, and a reload in front of a fragment read stalls the wave's MFMA stream.
+  unsigned aaddr[4][3];
+  auto make_aaddr = [&]() {
+    int xo = xl;
+    asm volatile("" : "+v"(xo));
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int hr = (2 * wave_u + d) * HW_ + xo + kw;
+        aaddr[d][kw] = lds0 + (unsigned)(hr * ROWB + ((half ^ swz(hr)) << 4));
+      }
+  };
+  make_aaddr();
+  // filter fragments: row xl (+ 32 j) of ring slot k, chunk c ^ swz(xl); the unit's tap t reads slot t % 4 of bslot[],
+  // which rotates by two per unit (18 taps)
+  unsigned bslot[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bslot[k] = lds0 + (unsigned)(B_OFF + k * TAPB + xl * ROWB + ((half ^ swz(xl)) << 4));
+
+  // pixel fragments of a k-half: [k-half set][row tile] hi and lo; filter fragments: two sets, alternating per column tile
+  f16x8 fah[2][2], fal[2][2], fbh[2], fbl[2];
+
+  // tap `tap_c` of the halo stage at immediate offset aoff_c: pixel fragment (row tile i, lo / hi) of k-half s into set s
+  auto read_a = [&](auto tap_c, auto s_c, auto i_c, auto lo_c, auto aoff_c) {
+    constexpr int tap = decltype(tap_c)::value, sk = decltype(s_c)::value, i = decltype(i_c)::value;
+    constexpr bool lo = decltype(lo_c)::value != 0;
+    constexpr int kh = tap / 3, kw = tap % 3;
+    const unsigned a = aaddr[i + kh][kw] ^ (unsigned)((lo ? 0x40 : 0) | (sk ? 0x20 : 0));
+    if constexpr (lo) fal[sk][i] = lds_read128i<decltype(aoff_c)::value>(a);
+    else fah[sk][i] = lds_read128i<decltype(aoff_c)::value>(a);
+  };
+  // filter fragment of column tile j, k-half s, from the ring slot at `base` into set `set`
+  auto read_b = [&](unsigned base, auto j_c, auto s_c, auto lo_c, auto set_c) {
+    constexpr int j = decltype(j_c)::value, sk = decltype(s_c)::value, set = decltype(set_c)::value;
+    constexpr bool lo = decltype(lo_c)::value != 0;
+    const unsigned b = base ^ (unsigned)((lo ? 0x40 : 0) | (sk ? 0x20 : 0));
+    if constexpr (lo) fbl[set] = lds_read128i<j * 4096>(b);
+    else fbh[set] = lds_read128i<j * 4096>(b);
+  };
+
+  __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.in2_bytes, 0x00020000);   // in2_bytes: size of `out` (halo launches)
+
+  f32x16 acc[TN][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][i][e] = 0.f;
+  };
+  zero_acc();
+
+  __builtin_amdgcn_s_barrier();                         // P
+  __builtin_amdgcn_sched_barrier(0);
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // first fragments of a tile's tap 0 (slice 0 = stage 0): pixel fragments of k-half 0 into set 0, filter fragments of
+  // (column tile 0, k-half 0) into set 0
+  auto first_frags = [&]() {
+    read_a(I0{}, I0{}, I0{}, I1{}, I0{}); read_a(I0{}, I0{}, I1{}, I1{}, I0{});
+    read_a(I0{}, I0{}, I0{}, I0{}, I0{}); read_a(I0{}, I0{}, I1{}, I0{}, I0{});
+    read_b(bslot[0], I0{}, I0{}, I0{}, I0{}); read_b(bslot[0], I0{}, I0{}, I1{}, I0{});
+  };
+  first_frags();
+
+  // One tap X = the tap's barrier, then 2 k-halves x TN column tiles x 6 MFMAs.  Group (s, j) uses pixel set s and filter
+  // set (s * TN + j) & 1 and, between its MFMAs, requests the NEXT group's filter fragments into the other filter set plus
+  // its share of the pixel fragments of the next k-half (k-half 1 of X during s = 0; k-half 0 of the next tap Y during
+  // s = 1) into the other pixel set: every register is rewritten a whole group after its last use.
+  auto tap_step = [&](auto tap_c, auto aoff_x, unsigned bx, auto ntap_c, auto aoff_n, unsigned bn) {
+    __builtin_amdgcn_s_barrier();                        // tap X's operands have landed (loaders); tap X - 1's slot is dead (this wave)
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 2>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      static_for<0, TN>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int gi = s * TN + j, set = gi & 1, nset = set ^ 1;
+        // This group's filter fragments were the first two reads of the previous group; the pixel fragments it requested
+        // after them (groups 0 and 1 of a k-half carry two each: all four of the next k-half are under way early) may
+        // still be in flight, except at a k-half's first group, which needs its pixel set complete.
+        if constexpr (j == 1 || (j == 2 && TN == 4)) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        auto mm = [&](int i, const f16x8& a, const f16x8& b) {
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j][i], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        auto rd_b = [&](auto lo_c) {                                // next group's filter fragments
+          if constexpr (j + 1 < TN) read_b(bx, std::integral_constant<int, j + 1>{}, sc, lo_c, std::integral_constant<int, nset>{});
+          else if constexpr (s == 0) read_b(bx, I0{}, I1{}, lo_c, std::integral_constant<int, nset>{});
+          else read_b(bn, I0{}, I0{}, lo_c, std::integral_constant<int, nset>{});
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        auto rd_a = [&](auto idx_c) {                               // next k-half's pixel fragments: lo 0, lo 1, hi 0, hi 1
+          constexpr int idx = decltype(idx_c)::value;
+          if constexpr (idx < 4) {
+            using IC = std::integral_constant<int, idx & 1>;
+            using LO = std::integral_constant<int, idx < 2 ? 1 : 0>;
+            if constexpr (s == 0) read_a(tap_c, I1{}, IC{}, LO{}, aoff_x);
+            else read_a(ntap_c, I0{}, IC{}, LO{}, aoff_n);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        mm(0, fal[s][0], fbh[set]); rd_b(I0{});
+        mm(1, fal[s][1], fbh[set]); rd_b(I1{});
+        mm(0, fah[s][0], fbl[set]); rd_a(std::integral_constant<int, j < 2 ? 2 * j : 4>{});
+        mm(1, fah[s][1], fbl[set]); rd_a(std::integral_constant<int, j < 2 ? 2 * j + 1 : 4>{});
+        mm(0, fah[s][0], fbh[set]);
+        mm(1, fah[s][1], fbh[set]);
+      });
+    });
+  };
+
+  // epilogue of the finished tile through a [256 pixels][32 channels] fp32 tile in halo stage 1 (just freed), one column
+  // tile at a time; a wave stages, reads back and stores only ITS OWN 64 pixels
+  auto epilogue = [&]() {
+    const int tile = xcd * per_x + it;                               // coordinates of the finished tile (scalar, recomputed: registers)
+    const int e_tx = tile % tiles_x, e_ty = (tile / tiles_x) % tiles_y;
+    const int e_ni = tile / (tiles_x * tiles_y), e_y0 = e_ty * TH, e_x0 = e_tx * TW;
+    const unsigned cs0 = lds0 + (unsigned)(A_BYTES + wave_u * 64 * 128);
+    const int eq = lane & 3, er = lane >> 2;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the last step's requests for the next tile's fragments
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      asm volatile("" ::: "memory");                                  // one column tile's constants at a time (registers)
+      __builtin_amdgcn_sched_barrier(0);
+      const int ccol = n * 32 + eq * 8;
+      const bool cvalid = ccol < p.cout;
+      f32x4 b8[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, w8[2] = {b8[0], b8[0]};
+      if (cvalid) {
+        if (p.bias != nullptr) { b8[0] = *reinterpret_cast<const f32x4*>(p.bias + ccol); b8[1] = *reinterpret_cast<const f32x4*>(p.bias + ccol + 4); }
+        w8[0] = *reinterpret_cast<const f32x4*>(p.wscale + ccol); w8[1] = *reinterpret_cast<const f32x4*>(p.wscale + ccol + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int row = i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+          lds_write32(cs0 + (unsigned)((row * 32 + xl) * 4), acc[n][i][rr]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int gp = 0; gp < (RES ? 2 : 4); ++gp) {                  // RES: two rows per round trip; else one (registers)
+        constexpr int GN = RES ? 2 : 1;
+        f32x4 va[GN], vb[GN];
+#pragma unroll
+        for (int g = 0; g < GN; ++g) {
+          const unsigned ra = cs0 + (unsigned)(((er + 16 * (GN * gp + g)) * 32 + eq * 8) * 4);
+          va[g] = lds_read128f(ra);
+          vb[g] = lds_read128f(ra + 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < GN; ++g) {
+          const int row = wave_u * 64 + er + 16 * (GN * gp + g);
+          const int y = e_y0 + (row >> 5), x = e_x0 + (row & 31);
+          const bool ok = cvalid && y < p.out_h && x < p.out_w;
+          const long m = ok ? ((long)e_ni * p.out_h + y) * p.out_w + x : 0;
+          float v[8] = {va[g][0], va[g][1], va[g][2], va[g][3], vb[g][0], vb[g][1], vb[g][2], vb[g][3]};
+          if constexpr (RES) {
+            float r1[8], r2[8];
+            if (p.res1 != nullptr) load8(p.res1, m, p.res1_ld, cvalid ? ccol : 0, p.res1_fmt, r1);
+            if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, cvalid ? ccol : 0, p.res2_fmt, r2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float t = v[e] * w8[e >> 2][e & 3] + b8[e >> 2][e & 3];
+              if (p.res1 != nullptr && p.res1_pre) t += r1[e];
+              t = t >= 0.f ? t : t * p.act_slope;
+              t = t * p.alpha;
+              if (p.res1 != nullptr && !p.res1_pre) t += r1[e];
+              if (p.res2 != nullptr) t = t * p.alpha2 + r2[e];
+              v[e] = t;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                   // the same expressions without the residual terms
+              float t = v[e] * w8[e >> 2][e & 3] + b8[e >> 2][e & 3];
+              t = t >= 0.f ? t : t * p.act_slope;
+              v[e] = t * p.alpha;
+            }
+          }
+          u32x4_t s0, s1;
+          unsigned o0, o1;
+          if (p.out_fmt == 1) {
+            split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, s0, s1);
+            o0 = (unsigned)(m * p.out_ld * 4 + split_chan_off(ccol));
+            o1 = o0 + 64u;
+          } else {
+            s0 = __builtin_bit_cast(u32x4_t, f32x4{v[0], v[1], v[2], v[3]});
+            s1 = __builtin_bit_cast(u32x4_t, f32x4{v[4], v[5], v[6], v[7]});
+            o0 = (unsigned)((m * p.out_ld + ccol) * 4);
+            o1 = o0 + 16u;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(s0, rs_out, ok ? o0 : 0xFFFFFFFFu, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(s1, rs_out, ok ? o1 : 0xFFFFFFFFu, 0, 0);
+        }
+      }
+      // the next column tile's staging overwrites what this wave has just read back: LDS accesses of a wave execute in order
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_barrier();                                   // E: every wave has read its pixels back: stage 1 may be refilled
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- main loop: units of 18 taps (two slices), every tap / stage / ring slot an immediate
+  int unit = 0;                                          // unit index inside the current tile
+  const int nunits = nslices / 2;
+  for (;;) {
+    if (unit != 0 || it != slot) make_aaddr();           // (the first unit's are in registers already)
+    static_for<0, 18>([&](auto tc) {
+      constexpr int t = decltype(tc)::value, tn = (t + 1) % 18;
+      using OX = std::integral_constant<int, (t / 9) * A_BYTES>;
+      using ON = std::integral_constant<int, (tn / 9) * A_BYTES>;
+      // tap t + 1 of the unit lives in slot (t + 1) % 4; the next unit's tap 0 (t = 17) in slot 18 % 4 = 2 of the current rotation
+      tap_step(std::integral_constant<int, t % 9>{}, OX{}, bslot[t % 4], std::integral_constant<int, tn % 9>{}, ON{}, bslot[(t + 1) % 4]);
+    });
+    {                                                    // 18 taps = 4 ring turns + 2: rotate the slot bases by two
+      const unsigned b0 = bslot[0], b1 = bslot[1];
+      bslot[0] = bslot[2]; bslot[1] = bslot[3]; bslot[2] = b0; bslot[3] = b1;
+    }
+    if (++unit == nunits) {
+      const int nit = it + slots, ntile = xcd * per_x + nit;
+      const bool more = nit < per_x && ntile < ntiles;
+      __builtin_amdgcn_sched_barrier(0);
+      epilogue();
+      if (!more) break;
+      it = nit;
+      unit = 0;
+      zero_acc();
+      // The last tap step requested the next tile's first fragments, but holding them across the epilogue costs 24
+      // registers the epilogue needs (the allocator spilled the fragment addresses instead): request them again here.
+      first_frags();
+    }
+  }
+}
+
 }  // namespace
 
 namespace fcp_conv {
@@ -457,6 +840,26 @@ int launch_f16x3_halo(const ConvK& k, hipStream_t s) {
   } else {
     FCP_LDS_OPT_IN(&conv3x3_halo_f16x3<2>, lds);
     hipLaunchKernelGGL(conv3x3_halo_f16x3<2>, dim3(grid), dim3(512), lds, s, k);
+  }
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+int launch_f16x3_halo_wide(const ConvK& k, hipStream_t s) {
+  const int tn = k.cout <= 64 ? 2 : 4;
+  const size_t lds = (size_t)(2 * A_BYTES + 4 * tn * 32 * ROWB);
+  const long tiles = (long)k.n * ((k.out_h + TH - 1) / TH) * ((k.out_w + TW - 1) / TW);
+  FCP_REQUIRE(tiles < (1L << 31), "conv(halo): too many tiles");
+  FCP_REQUIRE(k.ctiles >= 2 && k.ctiles % 2 == 0 && k.cout <= 128, "conv(halo, wide): cin must be a multiple of 64, cout <= 128");
+  FCP_REQUIRE(tn == 2 || (k.res1 == nullptr && k.res2 == nullptr), "conv(halo, wide): no residual inputs with more than 64 filters");
+  const int cus = fcp_cu_count();
+  const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
+  if (tn == 2) {
+    FCP_LDS_OPT_IN((&conv3x3_halo_wide_f16x3<2, true>), lds);
+    hipLaunchKernelGGL((conv3x3_halo_wide_f16x3<2, true>), dim3(grid), dim3(512), lds, s, k);
+  } else {
+    FCP_LDS_OPT_IN((&conv3x3_halo_wide_f16x3<4, false>), lds);
+    hipLaunchKernelGGL((conv3x3_halo_wide_f16x3<4, false>), dim3(grid), dim3(512), lds, s, k);
   }
   FCP_LAUNCH_OK();
   return 0;

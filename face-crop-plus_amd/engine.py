@@ -325,6 +325,10 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
               and pc.cout >= 128 and m >= 256 * 64)
     halo_ok = (pc.precision == 1 and x.fmt == 1 and not pc.cin4 and not in_up2 and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1)
                and pc.cout <= 64 and pc.cout % 8 == 0 and pc.cin >= 64 and x2 is None and (res1 is None or (res1.h, res1.w) == (oh, ow)))
+    # the wide halo-tile kernel (column tiles inner, filters through a tap ring): cin % 64 == 0, 65 .. 128 filters, no residuals
+    # (it also runs 33 .. 64 filters, tile (1, 64), where it merely ties with the pass-per-32-filters kernel: not offered)
+    wide_ok = (pc.precision == 1 and x.fmt == 1 and not pc.cin4 and not in_up2 and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1)
+               and pc.cout % 8 == 0 and pc.cin % 64 == 0 and x2 is None and 64 < pc.cout <= 128 and res1 is None and res2 is None)
     if tile_n is None and tile_m is None and (pc.cout > 64 or halo_ok) and (Autotune.enabled or Autotune.cache):
         key = (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, m, int(in_up2), res1 is not None, res2 is not None,
                pc.precision, x.fmt, out.fmt, None if x2 is None else (x2.c, x2_stride), d.cu_budget)
@@ -353,6 +357,8 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
             cands = [(128, 128), (128, 64)]
             if halo_ok:
                 cands = ([(128, 32)] if pc.cout <= 32 else []) + [(128, 64), (1, 32)]
+            if wide_ok and HALO_WIDE:
+                cands = cands + [(1, 128)]
             if big_ok and BIG_TILES:
                 big = [(256, 128)] + ([(256, 256)] if pc.cout >= 256 else []) + ([(256, 192)] if 128 < pc.cout <= 192 else [])
                 cands += big
@@ -411,6 +417,7 @@ def chain_supported(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, r
     return one(pc3, 128, 256) and one(pc1n, 256, 64)
 
 
+HALO_WIDE = os.environ.get("FCP_HALO_WIDE", "1") != "0"       # A/B switch: offer the wide halo-tile kernel to the tile tuner
 CHAIN_TILE_M = int(os.environ.get("FCP_CHAIN_TILE_M", "0"))   # 0 / 128: 4-wave tiles of 128 pixels; 256: 8-wave tiles where they fit
 
 

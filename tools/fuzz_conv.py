@@ -33,6 +33,8 @@ for case in range(cases):
         tiles += [(256, 128)] + ([(256, 256)] if cout >= 256 else []) + ([(256, 192)] if cout in (192, 320) else [])
     if k == 3 and stride == 1 and cout <= 64 and cin >= 64 and cout % 8 == 0:
         tiles += [(1, 32)]
+    if k == 3 and stride == 1 and cin % 64 == 0 and cout % 8 == 0 and (32 < cout <= 64 or (64 < cout <= 128 and not res)):
+        tiles += [(1, 64 if cout <= 64 else 128)]          # wide halo-tile kernel
     if cout % 8 != 0:
         continue
     # the 256-row kernel also with its balanced M-tile schedule, laid out for a small CU budget so that the few M-tiles of
