@@ -97,10 +97,12 @@ typedef struct fcp_conv_desc {
    * 32-channel group and in_ld / out_ld / res*_ld must be multiples of 32. */
   int32_t in_fmt, out_fmt, res1_fmt, res2_fmt;
   int32_t tile_m;     /* 0 / 128: 128-row workgroup tiles; 256: the 256-row, 8-wave kernel (precision 1,
-                         split32 input, no cin4 / in_up2; tile_n 128 or 256); 1: the halo-tile kernel
-                         for 3x3 / stride 1 / pad 1 convs with cout <= 64 (tile_n 32; tile_n 64 / 128: the wide form for cin % 64 == 0 and cout <= 64 / <= 128 without residuals; 8 x 32 pixel patches, precision 1,
-                         split32 input, cin >= 64, cout % 8 == 0, wscale / bias 16-byte aligned, |out view| < 4 GiB;
-                         tile_n ignored) */
+                         split32 input, no cin4 / in_up2; tile_n 128, 192 or 256); 1: the halo-tile kernels
+                         for 3x3 / stride 1 / pad 1 convs (8 x 32 pixel patches, precision 1, split32 input,
+                         cin >= 64, cout % 8 == 0, wscale / bias 16-byte aligned, |out view| < 4 GiB):
+                         tile_n 32 = one pass per 32 filters, cout <= 64; tile_n 64 / 128 = the wide form
+                         (column tiles inner, filters through a tap ring): cin % 64 == 0, cout <= 64, or
+                         cout <= 128 without residual inputs */
   /* Two-source 1x1 conv (K concatenation): the trailing cin2 of the cin input channels come from
    * in2, a split32 tensor (n, in2_h, in2_w, in2_ld) sampled at (ho*in2_stride, wo*in2_stride); the
    * leading cin - cin2 channels come from `in` as usual.  This is how a ResNet bottleneck's
