@@ -355,6 +355,49 @@ def test_conv_halo_tiles(cin, cout, hw, n, device, precision):
         E.conv(E.pack_conv(torch.randn(96, cin, 3, 3), None, None, 1, 1, device), xs, tile_m=1, tile_n=64)
 
 
+@pytest.mark.parametrize("cin,cout,hw,n", [(64, 128, (16, 64), 2), (128, 128, (19, 45), 1), (192, 96, (8, 32), 3), (64, 72, (5, 7), 2),
+                                           (256, 128, (40, 70), 2), (128, 128, (200, 300), 2), (64, 64, (9, 33), 1), (128, 40, (17, 20), 2),
+                                           (192, 64, (130, 260), 2)])
+def test_conv_halo_wide_tiles(cin, cout, hw, n, device, precision):
+    """The wide halo-tile kernel (tile_m=1, tile_n 64 / 128: pixel fragments kept across the column tiles, filters through a
+    four-slot tap ring, one barrier per tap): bit-identical to the implicit-GEMM tiles and to itself on a second run (no race
+    between the ring refills and the just-in-time fragment reads); 2 / 4 / 6 / 8 slices, ragged patches, more patches than
+    CUs (tiles chained across the persistent loop), residual epilogues for <= 64 filters, a rejected residual above."""
+    if precision != "f16x3":
+        pytest.skip("split32 tensors exist only on the fp16x3 path")
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(cin * 11 + cout)
+    h, w = hw
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    pc = E.pack_conv(wt, b, None, 1, 1, device)
+    xs = E.f32_to_split32(E.Act(_nhwc(x, device)))
+    tn = 64 if cout <= 64 else 128
+    ref = F.leaky_relu(F.conv2d(x, wt, b, 1, 1), 0.2) * 0.5
+    for fmt in ((0, 1) if cout % 32 == 0 else (0,)):
+        base = E.conv(pc, xs, act_slope=0.2, alpha=0.5, tile_m=128, tile_n=64, out_fmt=fmt)
+        assert (base.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+        out = E.conv(pc, xs, act_slope=0.2, alpha=0.5, tile_m=1, tile_n=tn, out_fmt=fmt)
+        assert torch.equal(out.buf, base.buf)
+        again = E.conv(pc, xs, act_slope=0.2, alpha=0.5, tile_m=1, tile_n=tn, out_fmt=fmt)
+        assert torch.equal(again.buf, out.buf)
+    res = E.Act(_nhwc(torch.randn(n, cout, h, w, generator=g), device))
+    if cout <= 64:
+        rs2 = E.Act(_nhwc(torch.randn(n, cout, h, w, generator=g), device))
+        if cout % 32 == 0:
+            rs2 = E.f32_to_split32(rs2)
+        a5 = E.conv(pc, xs, alpha=0.2, res1=res, res1_pre=False, res2=rs2, alpha2=0.2, out_fmt=int(cout % 32 == 0), tile_m=128, tile_n=64)
+        b5 = E.conv(pc, xs, alpha=0.2, res1=res, res1_pre=False, res2=rs2, alpha2=0.2, out_fmt=int(cout % 32 == 0), tile_m=1, tile_n=64)
+        assert torch.equal(a5.buf, b5.buf)
+    else:
+        with pytest.raises(RuntimeError, match="wide halo-tile"):
+            E.conv(pc, xs, res1=res, tile_m=1, tile_n=128)
+    with pytest.raises(RuntimeError, match="wide halo-tile"):    # cin must be a multiple of 64
+        E.conv(E.pack_conv(torch.randn(cout, 96, 3, 3), None, None, 1, 1, device),
+               E.f32_to_split32(E.Act(_nhwc(torch.randn(1, 96, 8, 8), device))), tile_m=1, tile_n=tn)
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 77, 91), (1, 64, 64), (3, 50, 130), (1, 9, 200), (2, 640, 640)])
 def test_fused_stem_pool(n, h, w, device, precision):
     """uint8 -> (x - mean) -> 7x7/2 conv + BN + ReLU -> max-pool 3x3/2 in one launch (RetinaFace stem, fp16x3 path):
