@@ -268,13 +268,13 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   FCP_REQUIRE(d->tile_m == 0 || d->tile_m == 128 || big || halo, "conv: tile_m must be 0/128/256 (or 1: halo-tile 3x3)");
   const bool halo_wide = halo && d->tile_n != 32;      // tile_n 64 / 128: column tiles inner, filters through a tap ring
   if (halo)
-    FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && !d->in_up2 && d->kh == 3 && d->kw == 3 && d->stride == 1 &&
+    FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && d->kh == 3 && d->kw == 3 && d->stride == 1 &&
                 d->pad == 1 && d->cout <= 64 && d->cout % 8 == 0 && d->cin >= 64 && !d->in2 &&
                 (!d->res1 || (d->res1_h == d->out_h && d->res1_w == d->out_w)) || halo_wide,
                 "conv: the halo-tile kernel needs a 3x3 / stride 1 / pad 1 conv with cin >= 64, cout <= 64 (cout %% 8 == 0) on the "
                 "fp16x3 path with a split32 input, no second source, no resized residual");
   if (halo_wide)
-    FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && !d->in_up2 && d->kh == 3 && d->kw == 3 && d->stride == 1 &&
+    FCP_REQUIRE(d->precision == 1 && d->in_fmt == 1 && !d->cin4 && d->kh == 3 && d->kw == 3 && d->stride == 1 &&
                 d->pad == 1 && d->cout % 8 == 0 && d->cin >= 64 && d->cin % 64 == 0 && !d->in2 &&
                 ((d->tile_n == 64 && d->cout <= 64 && (!d->res1 || (d->res1_h == d->out_h && d->res1_w == d->out_w))) ||
                  (d->tile_n == 128 && d->cout <= 128 && !d->res1 && !d->res2)),

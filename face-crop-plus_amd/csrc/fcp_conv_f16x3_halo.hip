@@ -1,4 +1,5 @@
-// fp16x3 3x3 convolution (stride 1, pad 1) for narrow outputs (cout <= 64): halo-tile implicit GEMM.
+// fp16x3 3x3 convolution (stride 1, pad 1) for narrow outputs (cout <= 64; the wide form below: <= 128): halo-tile implicit
+// GEMM.  The input may be the nearest x2 of the tensor in memory (in_up2: RRDB's upconv1 / upconv2, round 3).
 //
 // The generic kernels fetch a 128-byte operand row per output pixel, filter tap and 32-channel slice:
 // with N = 32 output channels that is 20 KiB of LDS-DMA per 6 MFMAs of a wave, and the RRDB dense
@@ -127,7 +128,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
       for (int i = 0; i < A_LD; ++i) {
         const int y = y0 - 1 + (hyx[i] >> 8), x = x0 - 1 + (hyx[i] & 255);
         const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)p.in_h && (unsigned)x < (unsigned)p.in_w;
-        abase[i] = ok ? ((unsigned)((ni * p.in_h + y) * p.in_w + x) * (unsigned)p.in_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
+        // in_up2: the logical input is the nearest x2 of the physical one (RRDB's upconv1 / upconv2): the halo row of logical
+        // pixel (y, x) is physical pixel (y / 2, x / 2); p.ph / p.pw are the physical sizes (= in_h / in_w otherwise)
+        const int yp = p.in_up2 ? y >> 1 : y, xp = p.in_up2 ? x >> 1 : x;
+        abase[i] = ok ? ((unsigned)((ni * p.ph + yp) * p.pw + xp) * (unsigned)p.in_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
       }
     };
     auto dma_halo = [&](int cs, int stage) {             // 11 (waves 0..2) / 10 (wave 3) instructions
@@ -508,7 +512,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_wide_f16x3(const ConvK p)
       for (int i = 0; i < A_LD; ++i) {
         const int y = y0 - 1 + (hyx[i] >> 8), x = x0 - 1 + (hyx[i] & 255);
         const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)p.in_h && (unsigned)x < (unsigned)p.in_w;
-        abase[i] = ok ? ((unsigned)((ni * p.in_h + y) * p.in_w + x) * (unsigned)p.in_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
+        // in_up2: the logical input is the nearest x2 of the physical one (RRDB's upconv1 / upconv2): the halo row of logical
+        // pixel (y, x) is physical pixel (y / 2, x / 2); p.ph / p.pw are the physical sizes (= in_h / in_w otherwise)
+        const int yp = p.in_up2 ? y >> 1 : y, xp = p.in_up2 ? x >> 1 : x;
+        abase[i] = ok ? ((unsigned)((ni * p.ph + yp) * p.pw + xp) * (unsigned)p.in_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
       }
     };
     constexpr int HALO_I = A_LD - 1;                      // halo instructions every loader wave issues (waves 0..2: one more)

@@ -124,6 +124,30 @@ def test_conv_upsampled_input(device):
     assert (out.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
 
 
+@pytest.mark.parametrize("cin,cout,hw,n", [(64, 64, (9, 11), 1), (64, 32, (20, 37), 2), (128, 128, (12, 40), 1), (64, 64, (70, 130), 2)])
+def test_conv_in_up2_halo_tiles(cin, cout, hw, n, device, precision):
+    """Nearest x2 fused into the operand fetch (RRDB's upconv1 / upconv2) on the halo-tile kernels: the staged halo row of a
+    logical pixel is the physical pixel (y / 2, x / 2).  Bit-identical to the implicit-GEMM tile, which has had it since round 1."""
+    if precision != "f16x3":
+        pytest.skip("split32 tensors exist only on the fp16x3 path")
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(cin + cout + hw[0])
+    h, w = hw
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.leaky_relu(F.conv2d(F.interpolate(x, scale_factor=2), wt, b, 1, 1), 0.2)
+    pc = E.pack_conv(wt, b, None, 1, 1, device)
+    xs = E.f32_to_split32(E.Act(_nhwc(x, device)))
+    base = E.conv(pc, xs, act_slope=0.2, in_up2=True, tile_m=128, tile_n=64)
+    assert (base.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
+    tiles = [(1, 32)] if cout <= 64 else []
+    tiles += [(1, 64)] if 32 < cout <= 64 else ([(1, 128)] if cout > 64 else [])
+    for tm, tn in tiles:
+        out = E.conv(pc, xs, act_slope=0.2, in_up2=True, tile_m=tm, tile_n=tn)
+        assert torch.equal(out.buf, base.buf), (tm, tn)
+
+
 @pytest.mark.parametrize("k,stride,pad", [(7, 2, 3), (3, 1, 1)])
 def test_conv_stem_cin4(k, stride, pad, device):
     """u8 image -> NHWC4 (mean subtraction fused) -> cin4-mode stem conv."""
