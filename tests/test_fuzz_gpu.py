@@ -1,6 +1,7 @@
 """Randomised cross-checks (tools/fuzz_conv.py, tools/fuzz_chain.py): every eligible geometry of the fp16x3 convolution
 engine returns the same bits and agrees with torch fp32; every fused bottleneck form returns the bits of the separate
-convolutions — on random shapes, strides, residuals, activations and output formats."""
+convolutions — on random shapes, strides, residuals, activations and output formats; the wide halo-tile kernel (loader / compute
+waves meeting at one barrier per tap) is launched repeatedly with other kernels in between (tools/fuzz_halo_wide.py)."""
 import os
 import subprocess
 import sys
@@ -11,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,cases,seed", [("fuzz_conv.py", 80, 11), ("fuzz_chain.py", 36, 12)])
+@pytest.mark.parametrize("tool,cases,seed", [("fuzz_conv.py", 80, 11), ("fuzz_chain.py", 36, 12), ("fuzz_halo_wide.py", 60, 13)])
 def test_randomised_bit_identity(tool, cases, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(cases), str(seed)], capture_output=True, text=True,
                        timeout=600, cwd=ROOT)
