@@ -464,9 +464,17 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
 // two per unit).  Same arithmetic and K order as every other fp16x3 kernel (per accumulator and k-half: al*bh, ah*bl,
 // ah*bh; slices outer, taps inner) => bit-identical results.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TN, bool RES>   // RES: the epilogue supports the two residual inputs (registers: only instantiated for TN = 2)
+// RES: the epilogue supports the two residual inputs (registers: only instantiated for TN = 2).  BT: taps per barrier
+// (a block), RS: ring slots.  With the taps of a block read just in time, an interval between two barriers touches the
+// slots of BT + 1 taps; the loaders, behind the barrier of block b, put the next BT taps of the stream into the slots of
+// block b - 1 and always run RS - BT taps ahead of the block being computed: (RS - BT - 1) / BT whole blocks of slack for a
+// DMA to land (2 => a loader waits only for what it issued BEFORE the previous barrier; 1 => for everything).
+template <int TN, bool RES, int BT, int RS>
 __global__ void __launch_bounds__(512, 1) conv3x3_halo_wide_f16x3(const ConvK p) {
   constexpr int TAPB = TN * 32 * ROWB;                // filter bytes of one tap: TN x 32 rows x 128 B
+  constexpr int PRE = RS - BT;                        // taps the loaders run ahead
+  constexpr bool SLACK2 = (RS - BT - 1) / BT >= 2;
+  static_assert(18 % BT == 0 && 18 % RS == 2 && (RS & (RS - 1)) == 0 && PRE >= BT + 1, "block / ring geometry");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = reinterpret_cast<char*>(smem);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -547,26 +555,35 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_wide_f16x3(const ConvK p)
     tile_setup(xcd * per_x + it);
     dma_halo(0, 0);
     dma_halo(1, 1);
-    dma_tap(0, 0); dma_tap(1, 1); dma_tap(2, 2);          // T >= 18
-    int g = 0;                                            // within-tile index of the tap whose barrier comes next
-    unsigned G = 0;                                       // the same, counted over the whole stream (ring slot = G % 4)
+#pragma unroll
+    for (int e = 0; e < PRE; ++e) dma_tap(e, e);            // T >= 18 > PRE
+    int g = 0;                                            // within-tile index of the first tap of the block whose barrier comes next
+    unsigned G = 0;                                       // the same, counted over the whole stream (ring slot = G % RS)
     int pend = 0;                                         // instructions issued behind the previous barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                         // P: slices 0, 1 and taps 0, 1, 2 are in LDS
+    __builtin_amdgcn_s_barrier();                         // P: slices 0, 1 and taps 0 .. PRE - 1 are in LDS
     for (;;) {
       const int nit = it + slots, ntile = xcd * per_x + nit;
       const bool more = nit < per_x && ntile < ntiles;
-      // everything issued before the previous barrier has landed (what was issued behind it may still fly)
-      if (pend >= TN + HALO_I) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN + HALO_I) : "memory");
-      else if (pend >= TN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                  // barrier of tap g: the slot of tap g - 1 is dead
+      if constexpr (SLACK2) {
+        // everything issued before the previous barrier has landed (what was issued behind it may still fly)
+        if (pend >= BT * TN + HALO_I) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BT * TN + HALO_I) : "memory");
+        else if (pend >= BT * TN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BT * TN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                                  // barrier of the block at tap g: the slots of the previous block are dead
       pend = 0;
-      const int t3 = g + 3;
-      if (t3 < T) { dma_tap(t3, (int)((G + 3u) & 3u)); pend += TN; }
-      else if (more) { dma_tap(t3 - T, (int)((G + 3u) & 3u)); pend += TN; }
-      if (g > 0 && g % 9 == 0) {                                     // tap g - 1 was tap 8 of slice g / 9 - 1: its stage takes the slice two ahead
-        const int died = g / 9 - 1, s2 = died + 2, stage = died & 1;
+#pragma unroll
+      for (int e = 0; e < BT; ++e) {
+        const int ta = g + PRE + e;                                    // filters do not depend on the tile: only its existence matters
+        if (ta < T) { dma_tap(ta, (int)((G + (unsigned)(PRE + e)) & (unsigned)(RS - 1))); pend += TN; }
+        else if (more) { dma_tap(ta - T, (int)((G + (unsigned)(PRE + e)) & (unsigned)(RS - 1))); pend += TN; }
+      }
+      const int t8 = (g / 9) * 9 - 1;                                // the last "tap 8 of a slice" before tap g
+      if (t8 >= 0 && t8 >= g - BT) {                                 // it was in the previous block: its stage takes the slice two ahead
+        const int died = t8 / 9, s2 = died + 2, stage = died & 1;
         if (s2 < nslices) { dma_halo(s2, stage); pend += HALO_I; }
         else if (more) {                                             // s2 == nslices: the next tile's first slice; its addresses replace this tile's
           tile_setup(ntile);
@@ -574,9 +591,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_wide_f16x3(const ConvK p)
           pend += HALO_I;
         }
       }
-      ++g; ++G;
+      g += BT; G += (unsigned)BT;
       if (g == T) {
-        // the tile's last tap is running; its last slice lives in stage 1, which hosts the epilogue before it is refilled
+        // the tile's last block is running; its last slice lives in stage 1, which hosts the epilogue before it is refilled
         __builtin_amdgcn_s_barrier();                                  // E: the compute waves have read the finished tile back from stage 1
         if (!more) return;
         dma_halo(1, 1);
@@ -607,9 +624,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_wide_f16x3(const ConvK p)
   make_aaddr();
   // filter fragments: row xl (+ 32 j) of ring slot k, chunk c ^ swz(xl); the unit's tap t reads slot t % 4 of bslot[],
   // which rotates by two per unit (18 taps)
-  unsigned bslot[4];
+  unsigned bslot[RS];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) bslot[k] = lds0 + (unsigned)(B_OFF + k * TAPB + xl * ROWB + ((half ^ swz(xl)) << 4));
+  for (int k = 0; k < RS; ++k) bslot[k] = lds0 + (unsigned)(B_OFF + k * TAPB + xl * ROWB + ((half ^ swz(xl)) << 4));
 
   // pixel fragments of a k-half: [k-half set][row tile] hi and lo; filter fragments: two sets, alternating per column tile
   f16x8 fah[2][2], fal[2][2], fbh[2], fbl[2];
@@ -663,9 +680,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_wide_f16x3(const ConvK p)
   // set (s * TN + j) & 1 and, between its MFMAs, requests the NEXT group's filter fragments into the other filter set plus
   // its share of the pixel fragments of the next k-half (k-half 1 of X during s = 0; k-half 0 of the next tap Y during
   // s = 1) into the other pixel set: every register is rewritten a whole group after its last use.
-  auto tap_step = [&](auto tap_c, auto aoff_x, unsigned bx, auto ntap_c, auto aoff_n, unsigned bn) {
-    __builtin_amdgcn_s_barrier();                        // tap X's operands have landed (loaders); tap X - 1's slot is dead (this wave)
-    __builtin_amdgcn_sched_barrier(0);
+  auto tap_step = [&](auto first_c, auto tap_c, auto aoff_x, unsigned bx, auto ntap_c, auto aoff_n, unsigned bn) {
+    if constexpr (decltype(first_c)::value != 0) {       // first tap of a block
+      __builtin_amdgcn_s_barrier();                      // the block's operands have landed (loaders); the previous block's slots are dead (this wave)
+      __builtin_amdgcn_sched_barrier(0);
+    }
     static_for<0, 2>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       static_for<0, TN>([&](auto jc) {
@@ -808,12 +827,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_wide_f16x3(const ConvK p)
       constexpr int t = decltype(tc)::value, tn = (t + 1) % 18;
       using OX = std::integral_constant<int, (t / 9) * A_BYTES>;
       using ON = std::integral_constant<int, (tn / 9) * A_BYTES>;
-      // tap t + 1 of the unit lives in slot (t + 1) % 4; the next unit's tap 0 (t = 17) in slot 18 % 4 = 2 of the current rotation
-      tap_step(std::integral_constant<int, t % 9>{}, OX{}, bslot[t % 4], std::integral_constant<int, tn % 9>{}, ON{}, bslot[(t + 1) % 4]);
+      // tap t + 1 of the unit lives in slot (t + 1) % RS; the next unit's tap 0 (t = 17) in slot 18 % RS = 2 of the current rotation
+      tap_step(std::integral_constant<int, t % BT == 0 ? 1 : 0>{}, std::integral_constant<int, t % 9>{}, OX{}, bslot[t % RS],
+               std::integral_constant<int, tn % 9>{}, ON{}, bslot[(t + 1) % RS]);
     });
-    {                                                    // 18 taps = 4 ring turns + 2: rotate the slot bases by two
+    {                                                    // 18 taps = whole ring turns + 2: rotate the slot bases by two
       const unsigned b0 = bslot[0], b1 = bslot[1];
-      bslot[0] = bslot[2]; bslot[1] = bslot[3]; bslot[2] = b0; bslot[3] = b1;
+      static_for<0, RS - 2>([&](auto kc) { bslot[decltype(kc)::value] = bslot[decltype(kc)::value + 2]; });
+      bslot[RS - 2] = b0; bslot[RS - 1] = b1;
     }
     if (++unit == nunits) {
       const int nit = it + slots, ntile = xcd * per_x + nit;
@@ -852,9 +873,14 @@ int launch_f16x3_halo(const ConvK& k, hipStream_t s) {
   return 0;
 }
 
+#ifndef FCP_WIDE2_BT
+#define FCP_WIDE2_BT 2
+#endif
+constexpr int WIDE2_BT = FCP_WIDE2_BT;   // taps per barrier of the 64-filter form (eight 8 KB slots); tools/wide2_ab.sh: RRDB conv5 610 / 586 / 605 us for 1 / 2 / 3
+
 int launch_f16x3_halo_wide(const ConvK& k, hipStream_t s) {
   const int tn = k.cout <= 64 ? 2 : 4;
-  const size_t lds = (size_t)(2 * A_BYTES + 4 * tn * 32 * ROWB);
+  const size_t lds = (size_t)(2 * A_BYTES + (tn == 2 ? 8 : 4) * tn * 32 * ROWB);   // TN = 2: eight 8 KB slots; TN = 4: four 16 KB slots
   const long tiles = (long)k.n * ((k.out_h + TH - 1) / TH) * ((k.out_w + TW - 1) / TW);
   FCP_REQUIRE(tiles < (1L << 31), "conv(halo): too many tiles");
   FCP_REQUIRE(k.ctiles >= 2 && k.ctiles % 2 == 0 && k.cout <= 128, "conv(halo, wide): cin must be a multiple of 64, cout <= 128");
@@ -862,11 +888,11 @@ int launch_f16x3_halo_wide(const ConvK& k, hipStream_t s) {
   const int cus = fcp_cu_count();
   const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
   if (tn == 2) {
-    FCP_LDS_OPT_IN((&conv3x3_halo_wide_f16x3<2, true>), lds);
-    hipLaunchKernelGGL((conv3x3_halo_wide_f16x3<2, true>), dim3(grid), dim3(512), lds, s, k);
+    FCP_LDS_OPT_IN((&conv3x3_halo_wide_f16x3<2, true, WIDE2_BT, 8>), lds);
+    hipLaunchKernelGGL((conv3x3_halo_wide_f16x3<2, true, WIDE2_BT, 8>), dim3(grid), dim3(512), lds, s, k);
   } else {
-    FCP_LDS_OPT_IN((&conv3x3_halo_wide_f16x3<4, false>), lds);
-    hipLaunchKernelGGL((conv3x3_halo_wide_f16x3<4, false>), dim3(grid), dim3(512), lds, s, k);
+    FCP_LDS_OPT_IN((&conv3x3_halo_wide_f16x3<4, false, 1, 4>), lds);
+    hipLaunchKernelGGL((conv3x3_halo_wide_f16x3<4, false, 1, 4>), dim3(grid), dim3(512), lds, s, k);
   }
   FCP_LAUNCH_OK();
   return 0;

@@ -326,7 +326,7 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     halo_ok = (pc.precision == 1 and x.fmt == 1 and not pc.cin4 and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1)
                and pc.cout <= 64 and pc.cout % 8 == 0 and pc.cin >= 64 and x2 is None and (res1 is None or (res1.h, res1.w) == (oh, ow)))
     # the wide halo-tile kernel (column tiles inner, filters through a tap ring): cin % 64 == 0, 65 .. 128 filters, no residuals
-    # (it also runs 33 .. 64 filters, tile (1, 64), where it merely ties with the pass-per-32-filters kernel: not offered)
+    # (it also runs 33 .. 64 filters, tile (1, 64): 586 vs 600 us alone on RRDB's conv5, nothing end to end: not offered)
     wide_ok = (pc.precision == 1 and x.fmt == 1 and not pc.cin4 and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1)
                and pc.cout % 8 == 0 and pc.cin % 64 == 0 and x2 is None and 64 < pc.cout <= 128 and res1 is None and res2 is None)
     if tile_n is None and tile_m is None and (pc.cout > 64 or halo_ok) and (Autotune.enabled or Autotune.cache):
