@@ -56,6 +56,7 @@ struct ConvK {
   // the launcher derives the rest.
   int balance, cu_budget;
   int mfull, tail_rows, round_size;
+  int stagger;          // 256-row kernel: first-round workgroups on odd CUs start `stagger` x ~4 us late (phase offset between CUs)
 };
 
 

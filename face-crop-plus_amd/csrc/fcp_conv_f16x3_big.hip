@@ -47,169 +47,6 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// Epilogue of one 256 x 128 half tile, 8 channels per lane, in two steps so that no lane ever waits for a single
-// load: (1) all residual rows of the half tile are requested at once, branch-free (clamped addresses), BEFORE the
-// accumulators are staged; (2) rows [crow + g*RPP] of the staged fp32 tile are combined with them and stored.  (A
-// per-row "if in range: load, use" loop compiles to one exposed HBM round trip per row.)
-constexpr int E_CPR = 128 / 8, E_RPP = NT / E_CPR, E_PASSES = BMB / E_RPP;   // 16 lanes per row, 32 rows per pass, 8 passes
-
-template <int NP>
-struct ResRows {
-  u32x4_t a[NP], b[NP];     // split32: hi, lo chunks; fp32: channels c..c+3, c+4..c+7
-};
-
-// passes [g0, g0 + NP) of the half tile
-template <int NP>
-__device__ __forceinline__ void load_res1_rows(const ConvK& p, int m_start, int m_end, int co_base, int co_end, int tid, int hw, int g0, ResRows<NP>& r) {
-  int co = co_base + (tid % E_CPR) * 8;
-  co = co < co_end ? co : 0;                                     // inactive lanes read a valid dummy
-  const long m0 = (long)m_start + tid / E_CPR;
-#pragma unroll
-  for (int g = 0; g < NP; ++g) {
-    long m = m0 + (long)(g0 + g) * E_RPP;
-    m = m < m_end ? m : (long)m_end - 1;
-    long rpix = m;
-    if (p.res1_resize) {
-      const int ni = (int)(m / hw);
-      const int rem = (int)(m - (long)ni * hw);
-      const int ho = rem / p.out_w;
-      const int wo = rem - ho * p.out_w;
-      int sh = (int)floorf(ho * p.res1_sh);
-      int sw = (int)floorf(wo * p.res1_sw);
-      sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
-      sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
-      rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
-    }
-    const char* pb = reinterpret_cast<const char*>(p.res1) + rpix * p.res1_ld * 4 +
-                     (p.res1_fmt == 1 ? split_chan_off(co) : (long)co * 4);
-    r.a[g] = *reinterpret_cast<const u32x4_t*>(pb);
-    r.b[g] = *reinterpret_cast<const u32x4_t*>(pb + (p.res1_fmt == 1 ? 64 : 16));
-  }
-}
-
-template <int NP>
-__device__ __forceinline__ void epilogue_rows(const ConvK& p, const float* Cs, int m_start, int m_end, int co_base, int co_end, int tid, int hw,
-                                              int g0, const ResRows<NP>& res) {
-  const int ccol = (tid % E_CPR) * 8;
-  const int crow = tid / E_CPR;
-  const int co = co_base + ccol;
-  if (co >= co_end) return;
-  const long m0 = (long)m_start + crow;
-  float bias8[8], ws8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bias8[e] = p.bias != nullptr ? p.bias[co + e] : 0.f;
-    ws8[e] = p.wscale[co + e];
-  }
-#pragma unroll
-  for (int g = 0; g < NP; ++g) {
-    const int row = crow + (g0 + g) * E_RPP;
-    const long m = m0 + (long)(g0 + g) * E_RPP;
-    float v[8], r1[8], r2[8];
-    {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * 128 + ccol);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * 128 + ccol + 4);
-      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-    }
-    if (p.res1 != nullptr) {
-      if (p.res1_fmt == 1) {
-        join8(res.a[g], res.b[g], r1);
-      } else {
-        const f32x4 fa = __builtin_bit_cast(f32x4, res.a[g]), fb = __builtin_bit_cast(f32x4, res.b[g]);
-        r1[0] = fa[0]; r1[1] = fa[1]; r1[2] = fa[2]; r1[3] = fa[3]; r1[4] = fb[0]; r1[5] = fb[1]; r1[6] = fb[2]; r1[7] = fb[3];
-      }
-    }
-    if (p.res2 != nullptr && m < m_end) load8(p.res2, m, p.res2_ld, co, p.res2_fmt, r2);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float x = v[e] * ws8[e] + bias8[e];
-      if (p.res1 != nullptr && p.res1_pre) x += r1[e];
-      x = x >= 0.f ? x : x * p.act_slope;
-      x = x * p.alpha;
-      if (p.res1 != nullptr && !p.res1_pre) x += r1[e];
-      if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
-      v[e] = x;
-    }
-    if (m >= m_end) continue;
-    if (p.out_fmt == 1) {
-      u32x4_t hi, lo;
-      split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
-      char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + split_chan_off(co);
-      *reinterpret_cast<u32x4_t*>(ob) = hi;
-      *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
-    } else {
-      float* dst = p.out + m * p.out_ld + co;
-      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    }
-  }
-}
-
-// Row-at-a-time variant (no extra registers): used by the 256-column tile, whose main loop has none to spare.
-__device__ __forceinline__ void epilogue_rows_seq(const ConvK& p, const float* Cs, int m_start, int m_end, int co_base, int co_end, int tid, int hw) {
-  constexpr int CPR = 128 / 8, RPP = NT / CPR, PASSES = BMB / RPP;
-  const int ccol = (tid % CPR) * 8;
-  const int crow = tid / CPR;
-  const int co = co_base + ccol;
-  if (co >= co_end) return;
-  const long m0 = (long)m_start + crow;
-  float bias8[8], ws8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bias8[e] = p.bias != nullptr ? p.bias[co + e] : 0.f;
-    ws8[e] = p.wscale[co + e];
-  }
-#pragma unroll 2
-  for (int g = 0; g < PASSES; ++g) {
-    const int row = crow + g * RPP;
-    const long m = m0 + (long)g * RPP;
-    if (m >= m_end) break;                       // rows ascend with g: nothing further belongs to this tile
-    float v[8], r1[8], r2[8];
-    {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * 128 + ccol);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * 128 + ccol + 4);
-      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-    }
-    if (p.res1 != nullptr) {
-      long rpix = m;
-      if (p.res1_resize) {
-        const int ni = (int)(m / hw);
-        const int rem = (int)(m - (long)ni * hw);
-        const int ho = rem / p.out_w;
-        const int wo = rem - ho * p.out_w;
-        int sh = (int)floorf(ho * p.res1_sh);
-        int sw = (int)floorf(wo * p.res1_sw);
-        sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
-        sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
-        rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
-      }
-      load8(p.res1, rpix, p.res1_ld, co, p.res1_fmt, r1);
-    }
-    if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, co, p.res2_fmt, r2);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float x = v[e] * ws8[e] + bias8[e];
-      if (p.res1 != nullptr && p.res1_pre) x += r1[e];
-      x = x >= 0.f ? x : x * p.act_slope;
-      x = x * p.alpha;
-      if (p.res1 != nullptr && !p.res1_pre) x += r1[e];
-      if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
-      v[e] = x;
-    }
-    if (p.out_fmt == 1) {
-      u32x4_t hi, lo;
-      split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
-      char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + split_chan_off(co);
-      *reinterpret_cast<u32x4_t*>(ob) = hi;
-      *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
-    } else {
-      float* dst = p.out + m * p.out_ld + co;
-      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    }
-  }
-}
-
 template <int BN>
 __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   constexpr int WAVES_N = BN == 256 ? 4 : 2;
@@ -239,6 +76,17 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   const int m_rows = tile_m < p.mfull ? BMB : p.tail_rows;
   const int m_end = m_start + m_rows < p.M ? m_start + m_rows : p.M;
 
+  // Phase offset between CUs.  One workgroup per CU and uniform tiles: every CU of the chip runs its main loop (operand
+  // reads) and then its epilogue (256 KB of stores per tile) at the same time, so the launch alternates between a read-only
+  // and a write-only phase of HBM with the matrix pipes idle in the second.  First-round workgroups on odd CUs start late.
+  if (p.stagger > 0 && bid < p.round_size) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+    if ((hw >> 8) & 1u)                                    // cu_id bit 0
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#ifdef FCP_BIG_PROBE
+  const unsigned long long ep_t0 = __builtin_readcyclecounter();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -398,9 +246,12 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
 #if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 2)
       asm volatile("" : "+v"(acc[i][j]) : "v"(fal[cs][i]), "v"(fah[cs][i]), "v"(fbh[cs][j]), "v"(fbl[cs][j]));
 #else
-      if constexpr (g == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[cs][i], fbh[cs][j], acc[i][j], 0, 0, 0);
-      else if constexpr (g == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[cs][i], fbl[cs][j], acc[i][j], 0, 0, 0);
-      else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[cs][i], fbh[cs][j], acc[i][j], 0, 0, 0);
+      // the filter fragment is the ROW operand: the tile is accumulated transposed (filters x pixels; same products, same
+      // K order, same bits), so that a lane ends up with four consecutive filters of ONE pixel per accumulator quad —
+      // what the LDS-free epilogue below needs
+      if constexpr (g == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[cs][j], fal[cs][i], acc[i][j], 0, 0, 0);
+      else if constexpr (g == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbl[cs][j], fah[cs][i], acc[i][j], 0, 0, 0);
+      else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[cs][j], fah[cs][i], acc[i][j], 0, 0, 0);
 #endif
       __builtin_amdgcn_sched_barrier(0);
       // read r is issued after MFMA floor((r + 1) * NM / NR) - 1
@@ -480,44 +331,125 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
            pc[0], pc[1], pc[2], pc[3]);
 #endif
   };
+#ifdef FCP_BIG_PROBE
+  const unsigned long long ep_t1 = __builtin_readcyclecounter();
+#endif
   static_for<0, TM + 1>([&](auto tc) {
     if (tm_act == decltype(tc)::value) main_loop(tc);
   });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#ifdef FCP_BIG_PROBE
+  const unsigned long long ep_t2 = __builtin_readcyclecounter();
+#endif
 
-  // ---- epilogue: 128 output columns at a time through a 256 x 128 fp32 LDS tile
-  float* Cs = smem;
-#pragma unroll 1
-  for (int h = 0; h < (BN + 127) / 128; ++h) {
-    // The 128-column tile requests all residual rows of the half tile at once, before staging the accumulators.
-    // The 256-column tile has no registers to spare (254 live in its main loop; any more and the allocator spills
-    // there), so it keeps the row-at-a-time epilogue: it is the kernel of the residual-free layers.
-    ResRows<E_PASSES> res;
-    // a pass covers 128 columns of the tile; the 192-column tile's second pass holds only 64 of its own
-    const int co_end = (tile_n + 1) * BN < p.cout ? (tile_n + 1) * BN : p.cout;
-    if (BN == 128 && p.res1 != nullptr) load_res1_rows<E_PASSES>(p, m_start, m_end, tile_n * BN + h * 128, co_end, tid, hw, 0, res);
+  // ---- epilogue, straight from the accumulators (no LDS, no barrier).  After the transposed accumulation lane l holds,
+  // for pixel (l & 31) of a 32 x 32 tile, filters 8 q + 4 (l >> 5) + 0..3 in accumulator quad q.  One v_permlane32_swap per
+  // register pairs quads (0, 1) and (2, 3) across the two half-waves: lanes 0..31 then hold filters 8 q0 .. 8 q0 + 7 of
+  // their pixel and lanes 32..63 filters 8 q1 .. 8 q1 + 7 of theirs — the eight consecutive channels of one 16-byte hi and
+  // one 16-byte lo store (or two fp32 stores), exactly the expressions of the staged epilogue (same bits).  The staged
+  // form (fp32 tile through LDS, two barriers and a row-at-a-time read-back per 128 columns) took 36 k cycles per 256 x 256
+  // tile with its stores ablated (`tools/big_epi_ablate.sh`): as much as 8-12 K slices of MFMAs.
+  {
+    const int hwv = lane >> 5;
+    long mrow[TM];
+    bool mok[TM];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col0 = wn * WTN + j * 32;               // this wave's j-th 32-column tile (WTN = 96 straddles the 128-column passes)
-      if (col0 / 128 != h) continue;
-      const int cbase = col0 - h * 128;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        if (i < tm_act)
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr) {
-            const int row = wm * WTM + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-            Cs[row * 128 + cbase + (lane & 31)] = acc[i][j][rr];
-          }
+    for (int i = 0; i < TM; ++i) {
+      const int m = m_start + wm * WTM + i * 32 + (lane & 31);
+      mok[i] = i < tm_act && m < m_end;
+      mrow[i] = mok[i] ? (long)m : (long)m_start;
     }
-    __syncthreads();
-    if constexpr (BN == 128)
-      epilogue_rows<E_PASSES>(p, Cs, m_start, m_end, tile_n * BN + h * 128, co_end, tid, hw, 0, res);
-    else
-      epilogue_rows_seq(p, Cs, m_start, m_end, tile_n * BN + h * 128, co_end, tid, hw);
-    __syncthreads();
+    const int co_tile = tile_n * BN;
+    const int co_end = (tile_n + 1) * BN < p.cout ? (tile_n + 1) * BN : p.cout;
+    static_for<0, TN>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      // this lane's two groups of eight channels in column tile j (pair 0: quads 0 / 1, pair 1: quads 2 / 3) and their constants
+      int co2[2];
+      bool cok2[2];
+      float bias8[2][8], ws8[2][8];
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        co2[pr] = co_tile + wn * WTN + j * 32 + 8 * (2 * pr + hwv);
+        cok2[pr] = co2[pr] < co_end;
+        const int cc = cok2[pr] ? co2[pr] : co_tile;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wscale + cc), w1 = *reinterpret_cast<const f32x4*>(p.wscale + cc + 4);
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (p.bias != nullptr) { b0 = *reinterpret_cast<const f32x4*>(p.bias + cc); b1 = *reinterpret_cast<const f32x4*>(p.bias + cc + 4); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ws8[pr][e] = w0[e]; ws8[pr][4 + e] = w1[e]; bias8[pr][e] = b0[e]; bias8[pr][4 + e] = b1[e]; }
+      }
+      static_for<0, TM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        // pair innermost: the four 32-byte pieces of a pixel's 128-byte line (hi / lo of channels 0-15, then of 16-31) leave
+        // back to back
+        static_for<0, 2>([&](auto prc) {
+          constexpr int pr = decltype(prc)::value;
+          const int co = co2[pr], cc = cok2[pr] ? co2[pr] : co_tile;
+          float v[8];
+          static_for<0, 4>([&](auto ec) {
+            constexpr int e = decltype(ec)::value;
+            // (through named floats: __builtin_bit_cast applied directly to a vector-element expression read element 0)
+            const float fa = acc[i][j][8 * pr + e], fb = acc[i][j][8 * pr + 4 + e];          // quads 2 pr and 2 pr + 1
+            unsigned qa = __float_as_uint(fa), qb = __float_as_uint(fb);
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));               // qa.upper <-> qb.lower
+            v[e] = __builtin_bit_cast(float, qa);
+            v[4 + e] = __builtin_bit_cast(float, qb);
+          });
+          const long m = mrow[i];
+          const bool ok = mok[i] && cok2[pr];
+          float r1[8], r2[8];
+          if (p.res1 != nullptr) {
+            long rpix = m;
+            if (p.res1_resize) {
+              const int ni = (int)(m / hw);
+              const int rem = (int)(m - (long)ni * hw);
+              const int ho = rem / p.out_w;
+              const int wo = rem - ho * p.out_w;
+              int sh = (int)floorf(ho * p.res1_sh);
+              int sw = (int)floorf(wo * p.res1_sw);
+              sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
+              sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
+              rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
+            }
+            load8(p.res1, rpix, p.res1_ld, cc, p.res1_fmt, r1);
+          }
+          if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, cc, p.res2_fmt, r2);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e] * ws8[pr][e] + bias8[pr][e];
+            if (p.res1 != nullptr && p.res1_pre) x += r1[e];
+            x = x >= 0.f ? x : x * p.act_slope;
+            x = x * p.alpha;
+            if (p.res1 != nullptr && !p.res1_pre) x += r1[e];
+            if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
+            v[e] = x;
+          }
+          if (ok) {
+            if (p.out_fmt == 1) {
+              u32x4_t hi, lo;
+              split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+              char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + split_chan_off(co);
+              *reinterpret_cast<u32x4_t*>(ob) = hi;
+              *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
+            } else {
+              float* dst = p.out + m * p.out_ld + co;
+              *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+              *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+          }
+        });
+      });
+    });
   }
+#ifdef FCP_BIG_PROBE
+  if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1 || blockIdx.x == gridDim.x / 2) && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ep_t3 = __builtin_readcyclecounter();
+    printf("workgroup %d of %d: prologue %llu, main loop %llu, epilogue (to the last store's completion) %llu cycles\n", (int)blockIdx.x, (int)gridDim.x,
+           ep_t1 - ep_t0, ep_t2 - ep_t1, ep_t3 - ep_t2);
+  }
+#endif
 }
 
 // M-tile schedule.  Uniform: ceil(M / 256) tiles of 256 rows.  Balanced (descriptor flag FCP_CONV_BALANCE_TAIL): the
@@ -528,12 +460,14 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
 // A launch with less than one round of uniform tiles is all "tail".  Results do not depend on the schedule.
 template <int BN>
 int launch(ConvK k, hipStream_t s) {
-  const size_t lds = 2 * (size_t)STAGE;   // two stages; the epilogue's 256 x 128 fp32 tile aliases them
+  const size_t lds = 2 * (size_t)STAGE;   // two stages (the epilogue works from the accumulators: no LDS tile)
   FCP_LDS_OPT_IN((&conv_igemm_f16x3_big<BN>), lds);
   k.grid_n = fcp_cdiv(k.cout, BN);
   int cus = k.cu_budget > 0 ? k.cu_budget : fcp_cu_count();
   cus = cus < 8 ? 8 : (cus & ~7);                                    // rounds are XCD-interleaved: a multiple of 8
   k.round_size = cus;
+  static const int stagger_env = getenv("FCP_BIG_STAGGER") ? atoi(getenv("FCP_BIG_STAGGER")) : 0;
+  k.stagger = stagger_env;
   const int mt = fcp_cdiv(k.M, BMB);
   k.mfull = mt;
   k.tail_rows = BMB;
