@@ -56,7 +56,8 @@ struct ConvK {
   // the launcher derives the rest.
   int balance, cu_budget;
   int mfull, tail_rows, round_size;
-  int stagger;          // 256-row kernel: first-round workgroups on odd CUs start `stagger` x ~4 us late (phase offset between CUs)
+  int big_tiles;        // 256-row kernel (persistent): tiles of the launch = virtual block ids 0 .. big_tiles - 1
+  int big_persist;      // 1: round_size workgroups walk the tiles; 0: one workgroup per tile
 };
 
 

@@ -63,30 +63,27 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   // and the M-tiles are `mfull` tiles of 256 rows followed by tiles of `tail_rows` rows: the last, partial round is
   // made of shorter tiles that together fill all CUs instead of full-height tiles on a fraction of them.  Splitting M
   // never changes a result: every output pixel still sees the same K loop.
-  const int nb = gridDim.x;
-  const int bid = blockIdx.x;
-  const int rbase = (bid / p.round_size) * p.round_size;
-  const int nr = nb - rbase < p.round_size ? nb - rbase : p.round_size;
-  const int bi = bid - rbase;
-  const int q8 = nr >> 3, r8 = nr & 7, xcd = bi & 7;
-  const int logical = rbase + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bi >> 3);
-  const int tile_n = logical % p.grid_n;
-  const int tile_m = logical / p.grid_n;
-  const int m_start = tile_m < p.mfull ? tile_m * BMB : p.mfull * BMB + (tile_m - p.mfull) * p.tail_rows;
-  const int m_rows = tile_m < p.mfull ? BMB : p.tail_rows;
-  const int m_end = m_start + m_rows < p.M ? m_start + m_rows : p.M;
+  // Persistent: the launch has one workgroup per CU it may count on (`round_size`); workgroup b works through the virtual
+  // block ids b, b + round_size, ... of the round-by-round schedule above (same tile -> XCD mapping as one workgroup per
+  // tile gave: round_size is a multiple of 8).  Between two tiles the next tile's first two K slices are requested BEFORE
+  // the finished tile's epilogue, so a tile no longer starts with an exposed DMA round trip (8-21 k cycles per tile).
+  const int nb = p.big_tiles;
+  int vb = blockIdx.x;
+  int tile_n = 0, m_start = 0, m_end = 0;
+  auto decode = [&](int bid) {
+    const int rbase = (bid / p.round_size) * p.round_size;
+    const int nr = nb - rbase < p.round_size ? nb - rbase : p.round_size;
+    const int bi = bid - rbase;
+    const int q8 = nr >> 3, r8 = nr & 7, xcd = bi & 7;
+    const int logical = rbase + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bi >> 3);
+    tile_n = logical % p.grid_n;
+    const int tile_m = logical / p.grid_n;
+    m_start = tile_m < p.mfull ? tile_m * BMB : p.mfull * BMB + (tile_m - p.mfull) * p.tail_rows;
+    const int m_rows = tile_m < p.mfull ? BMB : p.tail_rows;
+    m_end = m_start + m_rows < p.M ? m_start + m_rows : p.M;
+  };
+  decode(vb);
 
-  // Phase offset between CUs.  One workgroup per CU and uniform tiles: every CU of the chip runs its main loop (operand
-  // reads) and then its epilogue (256 KB of stores per tile) at the same time, so the launch alternates between a read-only
-  // and a write-only phase of HBM with the matrix pipes idle in the second.  First-round workgroups on odd CUs start late.
-  if (p.stagger > 0 && bid < p.round_size) {
-    const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
-    if ((hw >> 8) & 1u)                                    // cu_id bit 0
-      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-#ifdef FCP_BIG_PROBE
-  const unsigned long long ep_t0 = __builtin_readcyclecounter();
-#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,6 +94,8 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   const int hw = p.out_h * p.out_w;
   TapPiece tp[A_LD];
   unsigned base2[A_LD];   // second source of a 1x1 conv (channels >= csplit), or unused
+  unsigned woff[B_LD];
+  auto setup_tile = [&]() {                                      // operand addresses of the tile (tile_n, m_start, m_end)
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
     const int m = m_start + lrow + 64 * i;
@@ -117,13 +116,13 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     }
     tp[i] = make_tap_piece<false>(p, pbase, hi0, wi0, (unsigned)(csrc * 4));
   }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((tile_n * BN + lrow + 64 * i) * p.wrow + csrc * 4) * 4);
+  };
+  setup_tile();
   __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
-  unsigned woff[B_LD];
-#pragma unroll
-  for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((tile_n * BN + lrow + 64 * i) * p.wrow + csrc * 4) * 4);
-
   unsigned rowoff[A_LD];
   auto set_tap = [&](int tap, int kh_i, int kw_i) {
     const unsigned tapoff = (unsigned)((kh_i * p.pw + kw_i) * p.in_ld) * 4u;
@@ -176,12 +175,6 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   };
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // fragment addresses (stage 0); the stage toggles by XOR with STAGE
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -197,24 +190,22 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     bH[s] = brow + oh; bL[s] = brow + ol;
   }
 
-  // prologue: slices 0 and 1 in flight, slice 0 landed, its first k-half in F0
-  set_tap(0, 0, 0);
-  dma_slice(0, 0);
-  if (p.ktiles > 1) {
-    advance();
-    dma_slice(1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  // Rows of this tile the wave owns, in MFMA sub-tiles of 32: TM for a full tile, fewer (down to 0) in a tail tile.  The
+  // a tile's first two slices in flight (stages 0 and 1 are free: called at kernel start and after a tile's last barrier)
+  auto prefetch_tile = [&]() {
+    tap = 0; kh_i = 0; kw_i = 0; c0 = 0;
+    set_tap(0, 0, 0);
+    dma_slice(0, 0);
+    if (p.ktiles > 1) {
+      advance();
+      dma_slice(1, 1);
+    }
+  };
+  prefetch_tile();
+  // Rows of a tile the wave owns, in MFMA sub-tiles of 32: TM for a full tile, fewer (down to 0) in a tail tile.  The
   // main loop is instantiated per count (wave-uniform dispatch): a wave with fewer sub-tiles issues fewer MFMAs and
   // fragment reads but the same DMA share and the same barriers, so the two waves of a SIMD (w, w + 4: with the 256-column
   // tile they are the two row halves) split the matrix pipe of that SIMD in proportion to the rows that exist.
-  int tm_act = (m_end - m_start - wm * WTM + 31) >> 5;
-  tm_act = __builtin_amdgcn_readfirstlane(tm_act < 0 ? 0 : (tm_act > TM ? TM : tm_act));
+  int tm_act = 0;
   auto main_loop = [&](auto tma_c) {
     constexpr int TMA = decltype(tma_c)::value;
     f16x8 fah[2][TMA > 0 ? TMA : 1], fal[2][TMA > 0 ? TMA : 1], fbh[2][TN], fbl[2][TN];   // [fragment set]
@@ -331,18 +322,34 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
            pc[0], pc[1], pc[2], pc[3]);
 #endif
   };
-#ifdef FCP_BIG_PROBE
-  const unsigned long long ep_t1 = __builtin_readcyclecounter();
-#endif
+  for (;;) {
+  // slices 0 and 1 of this tile have landed (and, from the second tile on, the previous tile's stores have left)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  tm_act = (m_end - m_start - wm * WTM + 31) >> 5;
+  tm_act = __builtin_amdgcn_readfirstlane(tm_act < 0 ? 0 : (tm_act > TM ? TM : tm_act));
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   static_for<0, TM + 1>([&](auto tc) {
     if (tm_act == decltype(tc)::value) main_loop(tc);
   });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-#ifdef FCP_BIG_PROBE
-  const unsigned long long ep_t2 = __builtin_readcyclecounter();
-#endif
 
+  // the finished tile's coordinates; then the next tile's operand addresses and its first two slices, before the epilogue
+  const int e_tile_n = tile_n, e_m_start = m_start, e_m_end = m_end, e_tm_act = tm_act;
+  const bool more = p.big_persist && vb + p.round_size < nb;
+  if (more) {
+    vb += p.round_size;
+    decode(vb);
+    setup_tile();
+    prefetch_tile();
+  }
   // ---- epilogue, straight from the accumulators (no LDS, no barrier).  After the transposed accumulation lane l holds,
   // for pixel (l & 31) of a 32 x 32 tile, filters 8 q + 4 (l >> 5) + 0..3 in accumulator quad q.  One v_permlane32_swap per
   // register pairs quads (0, 1) and (2, 3) across the two half-waves: lanes 0..31 then hold filters 8 q0 .. 8 q0 + 7 of
@@ -356,12 +363,12 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     bool mok[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int m = m_start + wm * WTM + i * 32 + (lane & 31);
-      mok[i] = i < tm_act && m < m_end;
-      mrow[i] = mok[i] ? (long)m : (long)m_start;
+      const int m = e_m_start + wm * WTM + i * 32 + (lane & 31);
+      mok[i] = i < e_tm_act && m < e_m_end;
+      mrow[i] = mok[i] ? (long)m : (long)e_m_start;
     }
-    const int co_tile = tile_n * BN;
-    const int co_end = (tile_n + 1) * BN < p.cout ? (tile_n + 1) * BN : p.cout;
+    const int co_tile = e_tile_n * BN;
+    const int co_end = (e_tile_n + 1) * BN < p.cout ? (e_tile_n + 1) * BN : p.cout;
     static_for<0, TN>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       // this lane's two groups of eight channels in column tile j (pair 0: quads 0 / 1, pair 1: quads 2 / 3) and their constants
@@ -442,14 +449,8 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
       });
     });
   }
-#ifdef FCP_BIG_PROBE
-  if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1 || blockIdx.x == gridDim.x / 2) && tid == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long ep_t3 = __builtin_readcyclecounter();
-    printf("workgroup %d of %d: prologue %llu, main loop %llu, epilogue (to the last store's completion) %llu cycles\n", (int)blockIdx.x, (int)gridDim.x,
-           ep_t1 - ep_t0, ep_t2 - ep_t1, ep_t3 - ep_t2);
-  }
-#endif
+  if (!more) break;
+  }   // tiles of this workgroup
 }
 
 // M-tile schedule.  Uniform: ceil(M / 256) tiles of 256 rows.  Balanced (descriptor flag FCP_CONV_BALANCE_TAIL): the
@@ -466,8 +467,6 @@ int launch(ConvK k, hipStream_t s) {
   int cus = k.cu_budget > 0 ? k.cu_budget : fcp_cu_count();
   cus = cus < 8 ? 8 : (cus & ~7);                                    // rounds are XCD-interleaved: a multiple of 8
   k.round_size = cus;
-  static const int stagger_env = getenv("FCP_BIG_STAGGER") ? atoi(getenv("FCP_BIG_STAGGER")) : 0;
-  k.stagger = stagger_env;
   const int mt = fcp_cdiv(k.M, BMB);
   k.mfull = mt;
   k.tail_rows = BMB;
@@ -488,7 +487,14 @@ int launch(ConvK k, hipStream_t s) {
       }
     }
   }
-  hipLaunchKernelGGL((conv_igemm_f16x3_big<BN>), dim3(k.grid_m * k.grid_n), dim3(NT), lds, s, k);
+  k.big_tiles = k.grid_m * k.grid_n;
+  // Persistent only when the launch owns the device: with two detector streams (cu_budget = half the CUs each) a launch of
+  // cu_budget persistent workgroups cannot spread over the CUs the other stream leaves idle, and that costs more than the
+  // hidden tile prologues bring (same box, headline: 3514-3518 faces/s one workgroup per tile, 3256-3269 persistent; single
+  // stream 3318-3331 vs 3344-3349).  FCP_BIG_PERSIST=0 / 1 forces it off / on.
+  static const int persist_env = getenv("FCP_BIG_PERSIST") ? atoi(getenv("FCP_BIG_PERSIST")) : -1;
+  k.big_persist = persist_env < 0 ? (k.cu_budget == 0) : (persist_env != 0);
+  hipLaunchKernelGGL((conv_igemm_f16x3_big<BN>), dim3(k.big_persist && k.big_tiles > k.round_size ? k.round_size : k.big_tiles), dim3(NT), lds, s, k);
   FCP_LAUNCH_OK();
   return 0;
 }
