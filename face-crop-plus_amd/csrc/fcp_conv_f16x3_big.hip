@@ -369,6 +369,37 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     }
     const int co_tile = e_tile_n * BN;
     const int co_end = (e_tile_n + 1) * BN < p.cout ? (e_tile_n + 1) * BN : p.cout;
+    // first residual: its two 16-byte pieces (split32: hi / lo; fp32: channels c .. c+3 / c+4 .. c+7) are requested one
+    // (row tile, channel pair) ahead of their use — inline loads put one HBM round trip in front of every 8 channels
+    auto res1_raw = [&](int i, int cc, u32x4_t& ra, u32x4_t& rb) {
+      long rpix = mrow[i];
+      if (p.res1_resize) {
+        const long m = mrow[i];
+        const int ni = (int)(m / hw);
+        const int rem = (int)(m - (long)ni * hw);
+        const int ho = rem / p.out_w;
+        const int wo = rem - ho * p.out_w;
+        int sh = (int)floorf(ho * p.res1_sh);
+        int sw = (int)floorf(wo * p.res1_sw);
+        sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
+        sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
+        rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
+      }
+      if (p.res1_fmt == 1) {
+        const char* pb = reinterpret_cast<const char*>(p.res1) + rpix * p.res1_ld * 4 + split_chan_off(cc);
+        ra = *reinterpret_cast<const u32x4_t*>(pb);
+        rb = *reinterpret_cast<const u32x4_t*>(pb + 64);
+      } else {
+        ra = *reinterpret_cast<const u32x4_t*>(p.res1 + rpix * p.res1_ld + cc);
+        rb = *reinterpret_cast<const u32x4_t*>(p.res1 + rpix * p.res1_ld + cc + 4);
+      }
+    };
+    auto lane_cc = [&](int j, int pr) {                          // clamped first channel of (column tile j, pair pr) for this lane
+      const int co = co_tile + wn * WTN + j * 32 + 8 * (2 * pr + hwv);
+      return co < co_end ? co : co_tile;
+    };
+    u32x4_t nra = {0u, 0u, 0u, 0u}, nrb = nra;                    // the residual pieces of the NEXT (j, i, pr)
+    if (p.res1 != nullptr) res1_raw(0, lane_cc(0, 0), nra, nrb);
     static_for<0, TN>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       // this lane's two groups of eight channels in column tile j (pair 0: quads 0 / 1, pair 1: quads 2 / 3) and their constants
@@ -407,19 +438,16 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
           const bool ok = mok[i] && cok2[pr];
           float r1[8], r2[8];
           if (p.res1 != nullptr) {
-            long rpix = m;
-            if (p.res1_resize) {
-              const int ni = (int)(m / hw);
-              const int rem = (int)(m - (long)ni * hw);
-              const int ho = rem / p.out_w;
-              const int wo = rem - ho * p.out_w;
-              int sh = (int)floorf(ho * p.res1_sh);
-              int sw = (int)floorf(wo * p.res1_sw);
-              sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
-              sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
-              rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
+            const u32x4_t ra = nra, rb = nrb;
+            // request the next iteration's pieces: (i, pr + 1), (i + 1, 0) or (0, 0) of the next column tile
+            if constexpr (pr == 0) res1_raw(i, lane_cc(j, 1), nra, nrb);
+            else if constexpr (i + 1 < TM) res1_raw(i + 1, lane_cc(j, 0), nra, nrb);
+            else if constexpr (j + 1 < TN) res1_raw(0, lane_cc(j + 1, 0), nra, nrb);
+            if (p.res1_fmt == 1) join8(ra, rb, r1);
+            else {
+              const f32x4 fa = __builtin_bit_cast(f32x4, ra), fb = __builtin_bit_cast(f32x4, rb);
+              r1[0] = fa[0]; r1[1] = fa[1]; r1[2] = fa[2]; r1[3] = fa[3]; r1[4] = fb[0]; r1[5] = fb[1]; r1[6] = fb[2]; r1[7] = fb[3];
             }
-            load8(p.res1, rpix, p.res1_ld, cc, p.res1_fmt, r1);
           }
           if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, cc, p.res2_fmt, r2);
 #pragma unroll
