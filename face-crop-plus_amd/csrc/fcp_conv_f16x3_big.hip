@@ -351,108 +351,79 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     prefetch_tile();
   }
   // ---- epilogue, straight from the accumulators (no LDS, no barrier).  After the transposed accumulation lane l holds,
-  // for pixel (l & 31) of a 32 x 32 tile, filters 8 q + 4 (l >> 5) + 0..3 in accumulator quad q.  One v_permlane32_swap per
-  // register pairs quads (0, 1) and (2, 3) across the two half-waves: lanes 0..31 then hold filters 8 q0 .. 8 q0 + 7 of
-  // their pixel and lanes 32..63 filters 8 q1 .. 8 q1 + 7 of theirs — the eight consecutive channels of one 16-byte hi and
-  // one 16-byte lo store (or two fp32 stores), exactly the expressions of the staged epilogue (same bits).  The staged
-  // form (fp32 tile through LDS, two barriers and a row-at-a-time read-back per 128 columns) took 36 k cycles per 256 x 256
-  // tile with its stores ablated (`tools/big_epi_ablate.sh`): as much as 8-12 K slices of MFMAs.
+  // for pixel (l & 31) of a 32 x 32 tile, filters 8 q + 4 (l >> 5) + 0..3 in accumulator quad q.  Three lane permutations
+  // per register (v_permlane32_swap on the quads, then v_permlane32_swap + v_permlane16_swap on the results) leave lane
+  // (p = l & 15, g = l >> 4) with channels 8 g .. 8 g + 7 of pixel p (set A) and of pixel 16 + p (set B): one 16-byte hi
+  // and one 16-byte lo store per set, four neighbouring lanes filling the 64 bytes of a pixel's hi (lo) half — the store
+  // pattern of the staged epilogue, with its expressions (same bits), but no fp32 tile in LDS, no barrier and no read-back.
+  // The staged form took 36 k cycles per 256 x 256 tile with its stores ablated (`tools/big_epi_ablate.sh`): as much as
+  // 8-12 K slices of MFMAs.
   {
-    const int hwv = lane >> 5;
-    long mrow[TM];
-    bool mok[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = e_m_start + wm * WTM + i * 32 + (lane & 31);
-      mok[i] = i < e_tm_act && m < e_m_end;
-      mrow[i] = mok[i] ? (long)m : (long)e_m_start;
-    }
+    const int lp = lane & 15, lg = lane >> 4;
+    auto swap32 = [](float& x, float& y) {                          // x.lanes[32:63] <-> y.lanes[0:31]
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+      const unsigned r0 = r[0], r1 = r[1];
+      x = __uint_as_float(r0); y = __uint_as_float(r1);
+    };
+    auto swap16 = [](float& x, float& y) {                          // odd 16-lane rows of x <-> even rows of y
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+      const unsigned r0 = r[0], r1 = r[1];
+      x = __uint_as_float(r0); y = __uint_as_float(r1);
+    };
     const int co_tile = e_tile_n * BN;
     const int co_end = (e_tile_n + 1) * BN < p.cout ? (e_tile_n + 1) * BN : p.cout;
-    // first residual: its two 16-byte pieces (split32: hi / lo; fp32: channels c .. c+3 / c+4 .. c+7) are requested one
-    // (row tile, channel pair) ahead of their use — inline loads put one HBM round trip in front of every 8 channels
-    auto res1_raw = [&](int i, int cc, u32x4_t& ra, u32x4_t& rb) {
-      long rpix = mrow[i];
-      if (p.res1_resize) {
-        const long m = mrow[i];
-        const int ni = (int)(m / hw);
-        const int rem = (int)(m - (long)ni * hw);
-        const int ho = rem / p.out_w;
-        const int wo = rem - ho * p.out_w;
-        int sh = (int)floorf(ho * p.res1_sh);
-        int sw = (int)floorf(wo * p.res1_sw);
-        sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
-        sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
-        rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
-      }
-      if (p.res1_fmt == 1) {
-        const char* pb = reinterpret_cast<const char*>(p.res1) + rpix * p.res1_ld * 4 + split_chan_off(cc);
-        ra = *reinterpret_cast<const u32x4_t*>(pb);
-        rb = *reinterpret_cast<const u32x4_t*>(pb + 64);
-      } else {
-        ra = *reinterpret_cast<const u32x4_t*>(p.res1 + rpix * p.res1_ld + cc);
-        rb = *reinterpret_cast<const u32x4_t*>(p.res1 + rpix * p.res1_ld + cc + 4);
-      }
-    };
-    auto lane_cc = [&](int j, int pr) {                          // clamped first channel of (column tile j, pair pr) for this lane
-      const int co = co_tile + wn * WTN + j * 32 + 8 * (2 * pr + hwv);
-      return co < co_end ? co : co_tile;
-    };
-    u32x4_t nra = {0u, 0u, 0u, 0u}, nrb = nra;                    // the residual pieces of the NEXT (j, i, pr)
-    if (p.res1 != nullptr) res1_raw(0, lane_cc(0, 0), nra, nrb);
     static_for<0, TN>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      // this lane's two groups of eight channels in column tile j (pair 0: quads 0 / 1, pair 1: quads 2 / 3) and their constants
-      int co2[2];
-      bool cok2[2];
-      float bias8[2][8], ws8[2][8];
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        co2[pr] = co_tile + wn * WTN + j * 32 + 8 * (2 * pr + hwv);
-        cok2[pr] = co2[pr] < co_end;
-        const int cc = cok2[pr] ? co2[pr] : co_tile;
+      const int co = co_tile + wn * WTN + j * 32 + 8 * lg;            // this lane's eight channels in column tile j
+      const bool cok = co < co_end;
+      const int cc = cok ? co : co_tile;
+      float bias8[8], ws8[8];
+      {
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wscale + cc), w1 = *reinterpret_cast<const f32x4*>(p.wscale + cc + 4);
         f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
         if (p.bias != nullptr) { b0 = *reinterpret_cast<const f32x4*>(p.bias + cc); b1 = *reinterpret_cast<const f32x4*>(p.bias + cc + 4); }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ws8[pr][e] = w0[e]; ws8[pr][4 + e] = w1[e]; bias8[pr][e] = b0[e]; bias8[pr][4 + e] = b1[e]; }
+        for (int e = 0; e < 4; ++e) { ws8[e] = w0[e]; ws8[4 + e] = w1[e]; bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
       }
       static_for<0, TM>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        // pair innermost: the four 32-byte pieces of a pixel's 128-byte line (hi / lo of channels 0-15, then of 16-31) leave
-        // back to back
-        static_for<0, 2>([&](auto prc) {
-          constexpr int pr = decltype(prc)::value;
-          const int co = co2[pr], cc = cok2[pr] ? co2[pr] : co_tile;
-          float v[8];
-          static_for<0, 4>([&](auto ec) {
-            constexpr int e = decltype(ec)::value;
-            // (through named floats: __builtin_bit_cast applied directly to a vector-element expression read element 0)
-            const float fa = acc[i][j][8 * pr + e], fb = acc[i][j][8 * pr + 4 + e];          // quads 2 pr and 2 pr + 1
-            unsigned qa = __float_as_uint(fa), qb = __float_as_uint(fb);
-            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));               // qa.upper <-> qb.lower
-            v[e] = __builtin_bit_cast(float, qa);
-            v[4 + e] = __builtin_bit_cast(float, qb);
-          });
-          const long m = mrow[i];
-          const bool ok = mok[i] && cok2[pr];
+        float va[8], vb[8];                                           // sets A / B after the permutations
+        static_for<0, 4>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          // (named floats: __builtin_bit_cast applied directly to a vector-element expression read element 0)
+          float q0 = acc[i][j][e], q1 = acc[i][j][4 + e], q2 = acc[i][j][8 + e], q3 = acc[i][j][12 + e];
+          swap32(q0, q1);               // q0: ch e (lanes 0-31) | 8 + e (32-63);   q1: 4 + e | 12 + e           of pixel l & 31
+          swap32(q2, q3);               // q2: 16 + e | 24 + e;                     q3: 20 + e | 28 + e
+          swap32(q0, q2); swap16(q0, q2);   // q0 = set A: rows of 16 lanes hold ch e, 8 + e, 16 + e, 24 + e of pixels 0-15; q2 = set B (pixels 16-31)
+          swap32(q1, q3); swap16(q1, q3);   // the same for ch 4 + e, 12 + e, 20 + e, 28 + e
+          va[e] = q0; va[4 + e] = q1; vb[e] = q2; vb[4 + e] = q3;
+        });
+        static_for<0, 2>([&](auto sc) {
+          constexpr int set = decltype(sc)::value;
+          float (&v)[8] = set == 0 ? va : vb;
+          const int mi = e_m_start + wm * WTM + i * 32 + 16 * set + lp;
+          const bool ok = i < e_tm_act && mi < e_m_end && cok;
+          const long m = ok ? (long)mi : (long)e_m_start;
           float r1[8], r2[8];
           if (p.res1 != nullptr) {
-            const u32x4_t ra = nra, rb = nrb;
-            // request the next iteration's pieces: (i, pr + 1), (i + 1, 0) or (0, 0) of the next column tile
-            if constexpr (pr == 0) res1_raw(i, lane_cc(j, 1), nra, nrb);
-            else if constexpr (i + 1 < TM) res1_raw(i + 1, lane_cc(j, 0), nra, nrb);
-            else if constexpr (j + 1 < TN) res1_raw(0, lane_cc(j + 1, 0), nra, nrb);
-            if (p.res1_fmt == 1) join8(ra, rb, r1);
-            else {
-              const f32x4 fa = __builtin_bit_cast(f32x4, ra), fb = __builtin_bit_cast(f32x4, rb);
-              r1[0] = fa[0]; r1[1] = fa[1]; r1[2] = fa[2]; r1[3] = fa[3]; r1[4] = fb[0]; r1[5] = fb[1]; r1[6] = fb[2]; r1[7] = fb[3];
+            long rpix = m;
+            if (p.res1_resize) {
+              const int ni = (int)(m / hw);
+              const int rem = (int)(m - (long)ni * hw);
+              const int ho = rem / p.out_w;
+              const int wo = rem - ho * p.out_w;
+              int sh = (int)floorf(ho * p.res1_sh);
+              int sw = (int)floorf(wo * p.res1_sw);
+              sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
+              sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
+              rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
             }
+            load8(p.res1, rpix, p.res1_ld, cc, p.res1_fmt, r1);
           }
           if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, cc, p.res2_fmt, r2);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float x = v[e] * ws8[pr][e] + bias8[pr][e];
+            float x = v[e] * ws8[e] + bias8[e];
             if (p.res1 != nullptr && p.res1_pre) x += r1[e];
             x = x >= 0.f ? x : x * p.act_slope;
             x = x * p.alpha;
