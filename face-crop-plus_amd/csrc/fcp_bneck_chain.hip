@@ -417,8 +417,15 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   // 32-channel chunk.  A wave stages, finishes and re-reads (phase 3) only its own rows of the epilogue tile, so the three
   // steps of a chunk need no workgroup barrier between them and the four waves may drift apart inside a chunk (one wave's
   // MFMAs beside another's epilogue); what the waves share are the filter buffers: ONE barrier per chunk.
+#ifdef FCP_CHAIN_REG_EPI
+  // (register epilogue: after the lane permutations lane l holds channel group l >> 4 of rows (l & 15) and 16 + (l & 15);
+  //  a store instruction still covers 16 rows x 64 bytes)
+  const int eq = lane >> 4;
+  const int erow0 = wave * 32 + (lane & 15);
+#else
   const int eq = lane & 3;
   const int erow0 = wave * 32 + (lane >> 2);
+#endif
   const long em0 = (long)tile_m * BMT + erow0;
   long rm[2];                                                    // residual pixel of the two items (clamped)
   unsigned so[2];                                                // byte offset of the two items in `out`, 0xFFFFFFFF past the end
@@ -454,7 +461,15 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   const int nch = FCP_ABLATE(p, 8) ? 0 : NCH;
   f16x8 pch[2], pcl[2];                                          // rotated loop: T3 fragments of the previous chunk, per k-half
   f16x8 wx[ROT ? TN3 : 1], wy[ROT ? TN3 : 1];                    // rotated loop: conv1' fragments of the previous chunk's slice
+#ifdef FCP_CHAIN_REG_EPI
+  // this lane's eight conv3 channels of chunk 0 (channel group eq): scale and bias, requested a chunk ahead like the residual
+  f32x4 ws8a = *reinterpret_cast<const f32x4*>(p.ws3 + 8 * eq), ws8b = *reinterpret_cast<const f32x4*>(p.ws3 + 8 * eq + 4);
+  f32x4 b8a = *reinterpret_cast<const f32x4*>(p.b3 + 8 * eq), b8b = *reinterpret_cast<const f32x4*>(p.b3 + 8 * eq + 4);
+  constexpr int NCONST = 4;                                      // constant loads per chunk and thread (vmcnt bookkeeping below)
+#else
   float ws_l = p.ws3[l31], b_l = p.b3[l31];                      // this lane's conv3 channel of chunk 0 (MFMA layout: col = lane & 31)
+  constexpr int NCONST = 2;
+#endif
   f16x8 ah[CS][2], al[CS][2];                                    // phase-2 A fragments: the wave's own 32 rows of T2, [slice][k-half]
   auto read_a2 = [&]() {
 #pragma unroll
@@ -494,7 +509,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     // (W1DB false: group j was issued at top(j-1) and already forced by the wait in front of phase 3 of chunk j-1; the
     //  ops younger than that wait — c(j), R(j), S(j-1) — may all stay in flight, which is the same count)
     if (j == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NRES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NCONST + NRES) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -582,9 +597,15 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
         constexpr int q = decltype(tc)::value / 2, s = decltype(tc)::value % 2, sl = g * BG + q, trip = 2 * sl + s;
         static_for<0, 3>([&](auto ec) {
           constexpr int term = decltype(ec)::value;
+#ifdef FCP_CHAIN_REG_EPI   // transposed tile (filters x pixels: same products, same K order, same bits) for the register epilogue
+          if constexpr (term == 0) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[g & 1][q][s], al[sl][s], acc2, 0, 0, 0);
+          else if constexpr (term == 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[g & 1][q][s], ah[sl][s], acc2, 0, 0, 0);
+          else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[g & 1][q][s], ah[sl][s], acc2, 0, 0, 0);
+#else
           if constexpr (term == 0) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
           else if constexpr (term == 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[g & 1][q][s], acc2, 0, 0, 0);
           else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
+#endif
           if constexpr (ROT) {
             __builtin_amdgcn_sched_barrier(0);
             if (prev) static_for<0, PQ>([&](auto pc) { p3_step(std::integral_constant<int, (3 * trip + term) * PQ + decltype(pc)::value>{}); });
@@ -608,6 +629,36 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     // ---- acc2 * ws3 + b3 (per lane: one channel) -> the wave's rows of the fp32 tile.  Channel group q of a row is
     //      stored in the two 16-byte pieces the split32 image of that group will occupy (hi piece q ^ sw, lo piece
     //      (4 + q) ^ sw), so the epilogue rewrites each item in place.
+#ifdef FCP_CHAIN_REG_EPI
+    // ---- register epilogue (round 3): three lane permutations per accumulator register (v_permlane32_swap on the quads, then
+    //      v_permlane32_swap + v_permlane16_swap) leave lane (l & 15, l >> 4) with channels 8 eq .. 8 eq + 7 of rows
+    //      erow0 (va) and erow0 + 16 (vb); acc * ws3 + b3 below is the expression the staged form applied per channel.
+    //      No fp32 tile, no read-back: the staged form's round trip through LDS was 3-6 % of the chain launches
+    //      (an ablation bounded it).  Experiment builds only (FCP_CHAIN_REG_EPI): measured SLOWER than the staged form —
+    //      chains 1315 -> 1397 us, 128-wide pair 513 -> 565, layer-3 pair 443 -> 476 (tools/chain_epi_ab.sh): 24 lane permutations and
+    //      eight-channel constants per chunk cost more than 16 four-byte LDS writes and four 16-byte reads of the wave's own rows.
+    float va[8], vb[8];
+    {
+      auto swap32 = [](float& x, float& y) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        x = __uint_as_float(r0); y = __uint_as_float(r1);
+      };
+      auto swap16 = [](float& x, float& y) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        x = __uint_as_float(r0); y = __uint_as_float(r1);
+      };
+      static_for<0, 4>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        float q0 = acc2[e], q1 = acc2[4 + e], q2 = acc2[8 + e], q3 = acc2[12 + e];      // (named floats: see fcp_conv_f16x3_big.hip)
+        swap32(q0, q1); swap32(q2, q3);
+        swap32(q0, q2); swap16(q0, q2);
+        swap32(q1, q3); swap16(q1, q3);
+        va[e] = q0; va[4 + e] = q1; vb[e] = q2; vb[4 + e] = q3;
+      });
+    }
+#else
     {
       const int q = l31 >> 3;
 #pragma unroll
@@ -617,6 +668,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
         *reinterpret_cast<float*>(lds + CT_OFF + row * ROWB + (piece << 4) + (l31 & 3) * 4) = acc2[rr] * ws_l + b_l;
       }
     }
+#endif
     // ---- epilogue of conv3 for this chunk (own rows: LDS accesses of one wave execute in order, no barrier):
     //      out = relu(. + x) -> registers (stored in phase 3) and T3 (in place)
     __builtin_amdgcn_sched_barrier(0);
@@ -628,9 +680,18 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
       const int row = erow0 + 16 * it;
       const int sw = swz(row);
       char* crow = lds + CT_OFF + row * ROWB;
+#ifdef FCP_CHAIN_REG_EPI
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (it ? vb[e] : va[e]) * ws8a[e] + b8a[e];
+        v[4 + e] = (it ? vb[4 + e] : va[4 + e]) * ws8b[e] + b8b[e];
+      }
+#else
       const f32x4 a = *reinterpret_cast<const f32x4*>(crow + ((eq ^ sw) << 4));
       const f32x4 b = *reinterpret_cast<const f32x4*>(crow + (((4 + eq) ^ sw) << 4));
       float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#endif
       float r[8];
       if constexpr (HAS_RES) join8(rhi[it], rlo[it], r);
 #pragma unroll
@@ -648,15 +709,20 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     CPROBE(3);
     asm volatile("" ::: "memory");
     if (more) {                                                  // a chunk ahead: the lane's channel constants, the residual
+#ifdef FCP_CHAIN_REG_EPI
+      ws8a = *reinterpret_cast<const f32x4*>(p.ws3 + (j + 1) * 32 + 8 * eq); ws8b = *reinterpret_cast<const f32x4*>(p.ws3 + (j + 1) * 32 + 8 * eq + 4);
+      b8a = *reinterpret_cast<const f32x4*>(p.b3 + (j + 1) * 32 + 8 * eq); b8b = *reinterpret_cast<const f32x4*>(p.b3 + (j + 1) * 32 + 8 * eq + 4);
+#else
       ws_l = p.ws3[(j + 1) * 32 + l31];
       b_l = p.b3[(j + 1) * 32 + l31];
+#endif
       load_res(j + 1);
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     CPROBE(4);
     if constexpr (!W1DB) {                                       // single conv1' buffer: slice j was issued at the top
-      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NRES) : "memory");
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCONST + NRES) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
