@@ -12,9 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,cases,seed", [("fuzz_conv.py", 80, 11), ("fuzz_chain.py", 36, 12), ("fuzz_halo_wide.py", 60, 13)])
-def test_randomised_bit_identity(tool, cases, seed):
+@pytest.mark.parametrize("tool,cases,seed,env", [("fuzz_conv.py", 80, 11, {}), ("fuzz_chain.py", 36, 12, {}), ("fuzz_halo_wide.py", 60, 13, {}),
+                                                 # the 256-row kernel's persistent form with 8..64 workgroups walking many tiles each
+                                                 ("fuzz_conv.py", 60, 14, {"FCP_BIG_PERSIST": "1"})])
+def test_randomised_bit_identity(tool, cases, seed, env):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(cases), str(seed)], capture_output=True, text=True,
-                       timeout=600, cwd=ROOT)
+                       timeout=600, cwd=ROOT, env={**os.environ, **env})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.strip().endswith(f"{cases} cases, 0 bad"), r.stdout[-2000:]
