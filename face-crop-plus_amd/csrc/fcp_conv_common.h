@@ -1,6 +1,7 @@
 // Shared pieces of the convolution kernels (fp32-exact and fp16x3-split variants):
 // kernel parameter block and the fused epilogue.
 #pragma once
+#include <type_traits>
 #include "fcp_common.h"
 #include "fcp_hip.h"
 
@@ -318,6 +319,115 @@ __device__ __forceinline__ void prefetch_res1(const ConvK& p, int tile_m, int ti
       }
     }
   }
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void fcp_static_for(F&& f) {          // f(std::integral_constant<int, I>{}) for I .. N - 1
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    fcp_static_for<I + 1, N>(f);
+  }
+}
+
+// Epilogue straight from the accumulators of a TRANSPOSED tile (the filter fragment was the MFMA's row operand: filters x
+// pixels — same products, same K order, same bits as the pixel-major tile): no fp32 tile in LDS, no barrier, no read-back.
+// Lane l holds, for pixel (l & 31) of a 32 x 32 tile, filters 8 q + 4 (l >> 5) + 0..3 in accumulator quad q.  Three lane
+// permutations per register (v_permlane32_swap on the quads, then v_permlane32_swap + v_permlane16_swap on the results)
+// leave lane (p = l & 15, g = l >> 4) with channels 8 g .. 8 g + 7 of pixel p (set A) and of pixel 16 + p (set B): one
+// 16-byte hi and one 16-byte lo store per set, four neighbouring lanes filling the 64 bytes of a pixel's hi (lo) half —
+// the store pattern and the expressions of the staged epilogue (conv_epilogue8).  cout % 8 == 0, 16-byte aligned tensors.
+// Round 3: the staged form took 36 k cycles per 256 x 256 tile of the 256-row kernel with its stores ablated
+// (tools/big_epi_ablate.sh, profiles/r03_probes.md section 15).
+//   m_start / m_end: rows of the workgroup tile; tm_act: row tiles of this wave that exist (<= TM); co_tile / co_end: channels
+template <int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void conv_epilogue_regs(const ConvK& p, f32x16 (&acc)[TM][TN], int m_start, int m_end, int tm_act, int co_tile,
+                                                   int co_end, int wm, int wn, int lane, int hw) {
+    const int lp = lane & 15, lg = lane >> 4;
+  auto swap32 = [](float& x, float& y) {                          // x.lanes[32:63] <-> y.lanes[0:31]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    x = __uint_as_float(r0); y = __uint_as_float(r1);
+  };
+  auto swap16 = [](float& x, float& y) {                          // odd 16-lane rows of x <-> even rows of y
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    x = __uint_as_float(r0); y = __uint_as_float(r1);
+  };
+  fcp_static_for<0, TN>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int co = co_tile + wn * WTN + j * 32 + 8 * lg;            // this lane's eight channels in column tile j
+    const bool cok = co < co_end;
+    const int cc = cok ? co : co_tile;
+    float bias8[8], ws8[8];
+    {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wscale + cc), w1 = *reinterpret_cast<const f32x4*>(p.wscale + cc + 4);
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (p.bias != nullptr) { b0 = *reinterpret_cast<const f32x4*>(p.bias + cc); b1 = *reinterpret_cast<const f32x4*>(p.bias + cc + 4); }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ws8[e] = w0[e]; ws8[4 + e] = w1[e]; bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    }
+    fcp_static_for<0, TM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      float va[8], vb[8];                                           // sets A / B after the permutations
+      fcp_static_for<0, 4>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        // (named floats: __builtin_bit_cast applied directly to a vector-element expression read element 0)
+        float q0 = acc[i][j][e], q1 = acc[i][j][4 + e], q2 = acc[i][j][8 + e], q3 = acc[i][j][12 + e];
+        swap32(q0, q1);               // q0: ch e (lanes 0-31) | 8 + e (32-63);   q1: 4 + e | 12 + e           of pixel l & 31
+        swap32(q2, q3);               // q2: 16 + e | 24 + e;                     q3: 20 + e | 28 + e
+        swap32(q0, q2); swap16(q0, q2);   // q0 = set A: rows of 16 lanes hold ch e, 8 + e, 16 + e, 24 + e of pixels 0-15; q2 = set B (pixels 16-31)
+        swap32(q1, q3); swap16(q1, q3);   // the same for ch 4 + e, 12 + e, 20 + e, 28 + e
+        va[e] = q0; va[4 + e] = q1; vb[e] = q2; vb[4 + e] = q3;
+      });
+      fcp_static_for<0, 2>([&](auto sc) {
+        constexpr int set = decltype(sc)::value;
+        float (&v)[8] = set == 0 ? va : vb;
+        const int mi = m_start + wm * WTM + i * 32 + 16 * set + lp;
+        const bool ok = i < tm_act && mi < m_end && cok;
+        const long m = ok ? (long)mi : (long)m_start;
+        float r1[8], r2[8];
+        if (p.res1 != nullptr) {
+          long rpix = m;
+          if (p.res1_resize) {
+            const int ni = (int)(m / hw);
+            const int rem = (int)(m - (long)ni * hw);
+            const int ho = rem / p.out_w;
+            const int wo = rem - ho * p.out_w;
+            int sh = (int)floorf(ho * p.res1_sh);
+            int sw = (int)floorf(wo * p.res1_sw);
+            sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
+            sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
+            rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
+          }
+          load8(p.res1, rpix, p.res1_ld, cc, p.res1_fmt, r1);
+        }
+        if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, cc, p.res2_fmt, r2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e] * ws8[e] + bias8[e];
+          if (p.res1 != nullptr && p.res1_pre) x += r1[e];
+          x = x >= 0.f ? x : x * p.act_slope;
+          x = x * p.alpha;
+          if (p.res1 != nullptr && !p.res1_pre) x += r1[e];
+          if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
+          v[e] = x;
+        }
+        if (ok) {
+          if (p.out_fmt == 1) {
+            u32x4_t hi, lo;
+            split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+            char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + split_chan_off(co);
+            *reinterpret_cast<u32x4_t*>(ob) = hi;
+            *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
+          } else {
+            float* dst = p.out + m * p.out_ld + co;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          }
+        }
+      });
+    });
+  });
 }
 
 // Epilogue for 8-channel granularity: used whenever the output or a residual is in split32 format

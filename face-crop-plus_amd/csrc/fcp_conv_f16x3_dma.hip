@@ -19,7 +19,9 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int BN, int NST>
+// EP8: the output or a residual is split32 (cout % 8 == 0): the tile is accumulated transposed (filters x pixels — same bits) and
+// the epilogue works from the registers (conv_epilogue_regs); else the pixel-major tile and the staged fp32 epilogue.
+template <int BN, int NST, bool EP8>
 __global__ void __launch_bounds__(256, (BN == 128 ? 2 : 3)) conv_igemm_f16x3_dma(const ConvK p) {
   constexpr int WAVES_N = (BN == 32) ? 1 : 2;
   constexpr int WAVES_M = 4 / WAVES_N;
@@ -148,8 +150,7 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : 3)) conv_igemm_f16x3_dma
   // residual tile first: its HBM round trip overlaps the whole main loop
   ResPrefetch<BN> rpre;
   rpre.valid = false;
-  const bool ep8 = (p.out_fmt | p.res1_fmt | p.res2_fmt) != 0;
-  if (ep8) prefetch_res1<BN>(p, tile_m, tile_n, tid, rpre);
+  (void)rpre;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -217,9 +218,15 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : 3)) conv_igemm_f16x3_dma
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+          if constexpr (EP8) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s][j], al[s][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s][j], ah[s][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s][j], ah[s][i], acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+          }
         }
     __builtin_amdgcn_sched_barrier(0);   // keep the waits below behind the MFMAs ("memory" does not order MFMAs)
     // slice kt+1 must have landed before anyone reads it; with three stages the DMA issued in this
@@ -231,21 +238,29 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : 3)) conv_igemm_f16x3_dma
     if (++stage >= NST) stage = 0;
   }
 
-  if (ep8)
-    conv_epilogue8<BN, TM, TN, WTM, WTN>(p, acc, smem, tile_m, tile_n, tid, lane, wm, wn, hw, &rpre);
-  else
+  if constexpr (EP8) {
+    const int m_end = (tile_m + 1) * BM < p.M ? (tile_m + 1) * BM : p.M;
+    conv_epilogue_regs<TM, TN, WTM, WTN>(p, acc, tile_m * BM, m_end, TM, tile_n * BN, (tile_n + 1) * BN < p.cout ? (tile_n + 1) * BN : p.cout,
+                                         wm, wn, lane, hw);
+  } else {
     conv_epilogue<BN, TM, TN, WTM, WTN>(p, acc, smem, tile_m, tile_n, tid, lane, wm, wn, hw);
+  }
 }
 
-template <int BN, int NST>
-int launch(const ConvK& k, hipStream_t s) {
+template <int BN, int NST, bool EP8>
+int launch_ep(const ConvK& k, hipStream_t s) {
   size_t lds = (size_t)NST * (BM + BN) * 128;
-  const size_t epi = (size_t)BM * BN * 4;       // epilogue C tile
+  const size_t epi = EP8 ? 0 : (size_t)BM * BN * 4;       // the staged epilogue's C tile
   if (lds < epi) lds = epi;
-  FCP_LDS_OPT_IN((&conv_igemm_f16x3_dma<BN, NST>), lds);
-  hipLaunchKernelGGL((conv_igemm_f16x3_dma<BN, NST>), dim3(k.grid_m * k.grid_n), dim3(256), lds, s, k);
+  FCP_LDS_OPT_IN((&conv_igemm_f16x3_dma<BN, NST, EP8>), lds);
+  hipLaunchKernelGGL((conv_igemm_f16x3_dma<BN, NST, EP8>), dim3(k.grid_m * k.grid_n), dim3(256), lds, s, k);
   FCP_LAUNCH_OK();
   return 0;
+}
+template <int BN, int NST>
+int launch(const ConvK& k, hipStream_t s) {
+  const bool ep8 = (k.out_fmt | k.res1_fmt | k.res2_fmt) != 0;
+  return ep8 ? launch_ep<BN, NST, true>(k, s) : launch_ep<BN, NST, false>(k, s);
 }
 
 }  // namespace
