@@ -265,6 +265,7 @@ def _pmc_traffic(key):
         return round(json.load(f)["hbm_bytes_per_launch"]), "profiles/" + prof[-1]
 
 
+AUTOTUNE_ROOFLINE = True            # --no-autotune / FCP_AUTOTUNE=0 hold for the roofline passes too (recorded in the entry)
 LAUNCH_TABLE = None                 # --launch-table: CSV path for the per-launch table of the headline workload's roofline passes
 
 
@@ -281,7 +282,7 @@ def conv_roofline(p: Pipeline, nsteps, live, timed_ms=None, traffic_key=None, ta
         graphed, p.graphed = p.graphed, None          # per-launch events need the eager launches
         # the full-batch shapes of the single-stream pass are new to the tile tuner (the timed region tuned the
         # sub-batch shapes of its streams): tune them in an untimed step, like the timed region's initialisation pass
-        tuned, E.Autotune.enabled = E.Autotune.enabled, True
+        tuned, E.Autotune.enabled = E.Autotune.enabled, AUTOTUNE_ROOFLINE
         p.step(False)
         torch.cuda.synchronize()
         E.Autotune.enabled = tuned
@@ -313,7 +314,7 @@ def conv_roofline(p: Pipeline, nsteps, live, timed_ms=None, traffic_key=None, ta
            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
            # the split path executes 3 matrix FLOP per algorithmic FLOP: utilisation of the f16 pipe
            "executed_frac": round(achieved * (3 if split else 1) / peak, 4),
-           "streams": 1,
+           "streams": 1, "autotuned": bool(AUTOTUNE_ROOFLINE),
            "traffic": traffic,
            "traffic_unit": "HBM bytes per conv launch (PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
            "traffic_source": traffic_src,
@@ -466,20 +467,26 @@ def run_extra(dev, sds, args):
 
 def main():
     args = parse()
-    global LAUNCH_TABLE
+    global LAUNCH_TABLE, AUTOTUNE_ROOFLINE
     LAUNCH_TABLE = args.launch_table
+    AUTOTUNE_ROOFLINE = not args.no_autotune and os.environ.get("FCP_AUTOTUNE", "1") != "0"
     full = args.workload == "full"
     if args.batch is None:
         args.batch = 32 if full else 64
     if args.size is None:
         args.size = 1024 if full else 640
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                        # never returns: one rank per GPU under torch.distributed.run
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly one rank per GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible: refusing to run "
+                         f"{args.gpus} ranks on fewer devices")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -488,6 +495,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"RCCL group has {dist.get_world_size()} ranks, --gpus asked for {args.gpus}")
 
     from face_crop_plus_amd import weights
 
@@ -510,7 +519,7 @@ def main():
     elapsed = float(el.item())
     total_faces = int(faces.item())
 
-    roofline = cpu_baseline = extra = None
+    roofline = cpu_baseline = extra = parity_check = None
     hbm_kernels = None
     if rank == 0:
         std = not full and args.batch == 64 and args.size == 640
@@ -518,9 +527,12 @@ def main():
         roofline = conv_roofline(p, args.steps if live else args.roofline_steps, live,
                                  timed_ms=elapsed / args.steps * 1e3, traffic_key=key, table=True)
         if not args.graph:
-            hbm_kernels = hbm_kernel_records(p)
+            try:
+                hbm_kernels = hbm_kernel_records(p)
+            except Exception as e:                       # a side record must never take the headline line down
+                hbm_kernels = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(sd, p.images[:32].cpu(), args, p.tgt.cpu().numpy())
+        cpu_baseline, parity_check = run_cpu_baseline(sd, p.images[:32].cpu(), args, p.tgt.cpu().numpy(), p.last)
     describe = p.describe()
     if rank == 0 and world == 1 and not args.no_extra and not full:
         del p
@@ -533,7 +545,7 @@ def main():
         line = {
             "metric": "faces/sec end-to-end (detect+align+crop)",
             "value": round(total_faces / elapsed, 2), "unit": "faces/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else 0), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3" if args.precision == "f16x3" else "f32",
             "data": "synthetic (uniform uint8 images resident in HBM; seeded random-init weights; file I/O excluded)",
@@ -542,12 +554,30 @@ def main():
                        "faces_per_step": total_faces / max(args.steps, 1),
                        "images_per_s": round(args.batch * world * args.steps / elapsed, 2)},
             "roofline": roofline, "hbm_kernels": hbm_kernels, "cpu_baseline": cpu_baseline,
+            "parity_check": parity_check,
         }
         if extra is not None:
             line["extra"] = extra
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this command line as N ranks (one per GPU) under
+    torch.distributed.run on 127.0.0.1, so that a plain invocation can never fall through to a silent 1-rank run."""
+    import socket
+    import subprocess
+    if not torch.cuda.is_available() or torch.cuda.device_count() < n:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        raise SystemExit(f"--gpus {n} but only {have} GPU(s) are visible: refusing to run {n} ranks on fewer devices")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def host_cores():
@@ -583,9 +613,12 @@ def pick_cpu_threads():
     return best
 
 
-def run_cpu_baseline(sd, images_u8, args, tgt):
+def run_cpu_baseline(sd, images_u8, args, tgt, last=None):
     """The oracle (CPU restatement of the reference path, kind="port") on a bounded
-    sample of the same workload, all host cores."""
+    sample of the same workload, all host cores.  The oracle's outputs on those images are then used as the checker
+    of the timed batch itself (`parity_check`): selected-face indices must be equal, landmarks within 1e-3 px
+    (north_star's tolerance), and the GPU crops byte-equal to the oracle's estimate + warp of the GPU's landmarks
+    (cropper.py:514-547); the run fails otherwise."""
     from oracle import retinaface_ref as R, align_ref as A
     cores = pick_cpu_threads()
     torch.set_num_threads(cores)
@@ -595,14 +628,39 @@ def run_cpu_baseline(sd, images_u8, args, tgt):
         t = time.perf_counter()
         lm, idx = R.predict(x[:k], sd, args.strategy, 0.6)
         crops = A.crop_align(images_u8[:k].numpy(), None, idx, lm, tgt, (args.out_size, args.out_size), "constant")
-        return time.perf_counter() - t, len(crops)
+        return time.perf_counter() - t, len(crops), lm, idx
 
-    t1, _ = run(1)                       # warm-up + per-image cost estimate
+    t1, _, _, _ = run(1)                 # warm-up + per-image cost estimate
     k = int(max(2, min(images_u8.shape[0], args.cpu_seconds / max(t1, 1e-3))))
-    t, nf = run(k)
-    return {"value": round(nf / t, 3), "unit": "faces/s", "cores": cores, "kind": "port",
+    t, nf, lm_ref, idx_ref = run(k)
+    base = {"value": round(nf / t, 3), "unit": "faces/s", "cores": cores, "kind": "port",
             "sample": f"{k} images of the same synthetic {args.size}x{args.size} batch, torch-CPU fp32 + numpy oracle, "
                       f"{t:.1f} s wall"}
+    return base, (check_against_oracle(last, images_u8, k, lm_ref, idx_ref, tgt, args.out_size, A) if last is not None else None)
+
+
+def check_against_oracle(last, images_u8, k, lm_ref, idx_ref, tgt, out_size, A, pads=None):
+    """Outputs of the last timed step on images 0..k-1 against the oracle's on the same images."""
+    res, crops, ok = last
+    nf = int(res["face_offset"][-1].item())
+    idx = res["img_idx"][:nf].cpu().numpy()
+    sel = idx < k                                          # faces are ordered by image (retinaface.py:363-408)
+    lm = res["landmarks"][:nf].cpu().numpy()[sel]
+    idx_l = idx[sel].tolist()
+    indices_equal = idx_l == [int(i) for i in idx_ref]
+    err = float(np.abs(lm - np.asarray(lm_ref)).max()) if indices_equal and len(idx_l) else (0.0 if indices_equal else float("nan"))
+    okh = ok[:nf].cpu().numpy()[sel] != 0
+    crops_ref = A.crop_align(images_u8[:k].numpy(), pads, idx_l, lm, tgt, (out_size, out_size), "constant")
+    got = crops[:nf].cpu().numpy()[sel][okh]
+    differing = int((got != crops_ref).sum()) if got.shape == crops_ref.shape else -1
+    rec = {"images": k, "faces": len(idx_l), "indices_equal": bool(indices_equal), "max_landmark_err_px": err,
+           "tolerance_px": 1e-3, "crop_bytes_differing": differing, "crop_bytes_compared": int(got.size),
+           "checker": "oracle/retinaface_ref.predict + oracle/align_ref.crop_align on the first images of the timed batch "
+                      "(outputs of the last timed step)"}
+    if not indices_equal or not (err < 1e-3) or differing != 0:
+        print(json.dumps({"parity_check": rec}), file=sys.stderr, flush=True)
+        raise SystemExit("bench.py: the timed batch does not match the oracle (see parity_check on stderr)")
+    return rec
 
 
 if __name__ == "__main__":

@@ -73,6 +73,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         build_torch_ops(force, verbose)
     except Exception as e:                                  # noqa: BLE001 - compiler / header / ABI problems alike
         import warnings
+        # a veneer left over from an earlier build would become the default boundary (torch_ops auto mode) against a
+        # library whose structs may have changed: remove it, so that auto mode falls back to ctypes with its warning
+        if os.path.isfile(TORCH_LIB):
+            os.remove(TORCH_LIB)
         warnings.warn(f"libfcp_torch.so (torch.ops.fcp veneer) was not built: {e}")
     return LIB
 

@@ -75,9 +75,9 @@ class Cropper:
         self.num_std_landmarks = 5
         # host I/O threads of process_dir (decode prefetch + asynchronous encode/write around the GPU workers)
         self.io_threads = max(2, min(16, (os.cpu_count() or 4) // 2))
-        self._writer = None          # set by process_dir: executor the encoded files are written on
-        self._writes = None          # futures of the writes still in flight
-        self._write_slots = None     # back-pressure: bounds the in-flight writes
+        # set by process_dir as ONE tuple (executor the encoded files are written on, futures of the writes still in
+        # flight, semaphore bounding them), so that a task of a failed run can never see a half-reset state
+        self._io = None
         self._write_lock = Lock()
 
         if isinstance(self.output_size, int):
@@ -187,8 +187,7 @@ class Cropper:
         MAX_PENDING_WRITES tasks are in flight: a slow disk stalls the GPU worker here instead of piling uint8
         crops up in host memory, and a failed write surfaces at the next batch, not at the end of the run."""
         # Locals: process_dir resets the attributes when it unwinds, while tasks of a failed run may still be in flight.
-        writer = getattr(self, "_writer", None)
-        writes, slots = getattr(self, "_writes", None), getattr(self, "_write_slots", None)
+        writer, writes, slots = getattr(self, "_io", None) or (None, None, None)      # ONE read: never a torn triple
         if writer is None:
             write_image(path, pixels)
             return
@@ -342,8 +341,8 @@ class Cropper:
         from concurrent.futures import ThreadPoolExecutor
         depth = max(2, 2 * self.num_processes)
         io = ThreadPoolExecutor(max_workers=self.io_threads, thread_name_prefix="fcp-io")
-        self._writer, self._writes = io, []
-        self._write_slots = BoundedSemaphore(self.MAX_PENDING_WRITES)
+        writes = []
+        self._io = (io, writes, BoundedSemaphore(self.MAX_PENDING_WRITES))
         # every file is its own decode task (a batch decoded by one thread would cap the pipeline at `depth` decoders)
         def submit_read(i):
             return [io.submit(read_image, os.path.join(input_dir, f)) for f in file_batches[i]]
@@ -387,8 +386,8 @@ class Cropper:
                     except ImportError:
                         pass
                 list(imap)
-            for w in self._writes:
+            for w in writes:
                 w.result()                       # surface encode / write errors
         finally:
             io.shutdown(wait=True)       # in-flight tasks still hold the semaphore / list: reset only afterwards
-            self._writer, self._writes, self._write_slots = None, None, None
+            self._io = None

@@ -317,6 +317,10 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
     SPROBE(5);
     if constexpr (HAS_C1) {
       lds_barrier();                                    // conv1 operand complete; the stem stage is no longer read
+      // INVARIANT: c1in rows of pooled pixels outside the image (and rows 80..95) are never written and hold stale LDS —
+      // possibly NaN / Inf bit patterns.  That is harmless only because the tile is accumulated TRANSPOSED (filters x
+      // pixels): a pixel's operand row feeds exactly one accumulator column, and the columns of those rows are never
+      // stored.  Any cross-pixel reduction or a change of the tile orientation must zero c1in first.
       if (c1rt < 3) {
         f32x16 acc;
 #pragma unroll

@@ -306,6 +306,11 @@ TORCH_LIBRARY(fcp, m) {
   m.def("warp_affine_u8(Tensor images, Tensor img_idx, Tensor mat, Tensor? ok, Tensor? paddings, int out_w, int out_h, int border) -> Tensor");
   m.def("bicubic_down4_round(Tensor x4) -> Tensor");
   m.def("parse_argmax_hist(Tensor logits, int ncls, int mid_h, int mid_w, int out_h, int out_w) -> (Tensor, Tensor)");
+  // ABI the veneer was COMPILED against (struct layouts of include/fcp_hip.h) and the ABI of the libfcp_hip.so it is
+  // running on: torch_ops.load() refuses a stale veneer (its shorter structs would be read past their end)
+  m.def("abi_version() -> (int, int)", []() -> std::tuple<int64_t, int64_t> {
+    return {(int64_t)FCP_ABI_VERSION, (int64_t)fcp_abi_version()};
+  });
 }
 
 TORCH_LIBRARY_IMPL(fcp, CUDA, m) {

@@ -47,6 +47,11 @@ def load():
             raise RuntimeError(f"torch op library not built: {LIB_PATH} is missing "
                                f"(run `python face-crop-plus_amd/build_native.py`)")
         torch.ops.load_library(LIB_PATH)
+        from ._native import ABI_VERSION
+        built, running = torch.ops.fcp.abi_version()
+        if built != ABI_VERSION or running != ABI_VERSION:
+            raise RuntimeError(f"libfcp_torch.so is stale: compiled against ABI {built}, libfcp_hip.so reports {running}, "
+                               f"host code expects {ABI_VERSION}; rebuild (python face-crop-plus_amd/build_native.py --force)")
         _loaded = True
     return torch.ops.fcp
 

@@ -165,6 +165,10 @@ _ENCODER_KW = {
 }
 
 
+_NOT_CV2_FORMATS = {"GIF", "PDF", "ICO", "ICNS", "PALM", "MPO", "XBM", "IM", "MSP", "PCX", "DDS", "TGA", "SGI", "EPS", "SPIDER",
+                    "BLP", "BUFR", "GRIB", "HDF5", "DIB", "APNG"}   # Pillow writes them, cv2.imwrite refuses: skipped like there
+
+
 def write_image(path: str, image: np.ndarray) -> bool:
     """RGB (or single-channel mask) uint8 array -> file; format from the extension, ``cv2.imwrite`` defaults for the
     formats listed above, Pillow's own choice of encoder for every other extension it knows (.ppm / .pgm / .pnm /
@@ -175,11 +179,20 @@ def write_image(path: str, image: np.ndarray) -> bool:
     if kw is not None:
         Image.fromarray(image).save(path, **kw)
         return True
-    try:
-        Image.fromarray(image).save(path)          # format inferred from the extension
-    except (ValueError, KeyError, OSError) as e:    # unknown extension / encoder plug-in not built into this Pillow
-        if os.path.exists(path) and os.path.getsize(path) == 0:
-            os.remove(path)
-        warnings.warn(f"Could not write the image {path}: {e}")
+    ext = os.path.splitext(path)[1].lower()
+    Image.init()                                    # fill Pillow's extension -> encoder registry
+    fmt = Image.registered_extensions().get(ext)
+    if fmt is None or fmt.upper() not in Image.SAVE or fmt.upper() in _NOT_CV2_FORMATS:
+        # no encoder for this extension (here or in cv2.imwrite): the reference's writer returns False and goes on
+        warnings.warn(f"Could not write the image {path}: no encoder for the extension {ext!r}")
         return False
+    # real I/O errors (disk full, permissions, a missing directory) propagate, like everywhere else in the writer; the
+    # file goes to a temporary name first so that a failed write never leaves a truncated image behind
+    tmp = f"{path}.part{os.getpid()}"
+    try:
+        Image.fromarray(image).save(tmp, format=fmt)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return True

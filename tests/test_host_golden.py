@@ -126,7 +126,7 @@ def test_save_group_paths_match_reference(plumb, tmp_path, monkeypatch):
     written = []
     monkeypatch.setattr(CR, "write_image", lambda path, img: written.append(os.path.relpath(path, tmp_path)))
     c = CR.Cropper.__new__(CR.Cropper)
-    c._writer = c._writes = None
+    c._io = None
     faces = [np.zeros((4, 4, 3), np.uint8)] * 5 + [np.zeros((4, 4), np.uint8)]
     names = np.array(["a.jpg", "a.jpg", "b.png", "a.jpg", "c.jpeg", "b.png"])
     for strategy, fmt in (("all", None), ("largest", None), ("all", "png"), ("best", "jpg")):

@@ -65,6 +65,19 @@ def test_extensions_outside_the_tuned_table_still_write(tmp_path):
             assert np.array_equal(back, arr), name
 
 
+def test_write_errors_propagate_and_leave_no_partial_file(tmp_path):
+    """Only "no encoder for this extension" is warn-and-skip (what cv2.imwrite's False becomes, cropper.py:605-609);
+    a real I/O error raises, no truncated file stays behind, and formats cv2.imwrite refuses (.gif) are not written."""
+    from face_crop_plus_amd.utils import write_image
+    img = _smooth()
+    with pytest.raises(OSError):
+        write_image(str(tmp_path / "no_such_dir" / "a.ppm"), img)
+    assert os.listdir(tmp_path) == []
+    with pytest.warns(UserWarning, match="no encoder"):
+        assert write_image(str(tmp_path / "a.gif"), img) is False
+    assert os.listdir(tmp_path) == []
+
+
 def test_emit_after_process_dir_unwinds(tmp_path):
     """A write task still in flight when process_dir's attributes are reset must finish (it holds its own references),
     and a slot is given back when the executor refuses the task."""
@@ -72,16 +85,15 @@ def test_emit_after_process_dir_unwinds(tmp_path):
     from concurrent.futures import ThreadPoolExecutor
     import face_crop_plus_amd.cropper as CR
     c = CR.Cropper.__new__(CR.Cropper)
-    c._writer, c._writes = ThreadPoolExecutor(2), []
-    c._write_slots, c._write_lock = threading.BoundedSemaphore(2), threading.Lock()
-    ex, writes, slots = c._writer, c._writes, c._write_slots
+    ex, writes, slots = ThreadPoolExecutor(2), [], threading.BoundedSemaphore(2)
+    c._io, c._write_lock = (ex, writes, slots), threading.Lock()
     c._emit(str(tmp_path / "a.png"), np.zeros((2, 2, 3), np.uint8))
-    c._writer, c._writes, c._write_slots = None, None, None       # what process_dir's finally block does
+    c._io = None                                                   # what process_dir's finally block does
     for w in writes:
         w.result()                                                 # no AttributeError inside the task
     assert (tmp_path / "a.png").exists()
     ex.shutdown(wait=True)
-    c._writer, c._writes, c._write_slots = ex, writes, slots
+    c._io = (ex, writes, slots)
     with pytest.raises(RuntimeError):                              # submit after shutdown
         c._emit(str(tmp_path / "b.png"), np.zeros((2, 2, 3), np.uint8))
     assert slots.acquire(blocking=False) and slots.acquire(blocking=False)     # both slots are free again
@@ -158,8 +170,7 @@ def test_bounded_async_writes(tmp_path, monkeypatch):
     monkeypatch.setattr(CR, "write_image", slow_write)
     c = CR.Cropper.__new__(CR.Cropper)
     c.MAX_PENDING_WRITES = 3
-    c._writer, c._writes = ThreadPoolExecutor(8), []
-    c._write_slots, c._write_lock = threading.BoundedSemaphore(3), threading.Lock()
+    c._io, c._write_lock = (ThreadPoolExecutor(8), [], threading.BoundedSemaphore(3)), threading.Lock()
     c.strategy, c.output_format = "largest", None
     t = threading.Thread(target=lambda: c.save_group([np.zeros((2, 2, 3), np.uint8)] * 6,
                                                      np.array([f"f{i}.png" for i in range(6)]), str(tmp_path)))
@@ -170,11 +181,11 @@ def test_bounded_async_writes(tmp_path, monkeypatch):
     t.join(5)
     assert not t.is_alive() and peak[0] == 3
     c._emit(str(tmp_path / "boom.png"), np.zeros((2, 2, 3), np.uint8))
-    for w in list(c._writes):
+    for w in list(c._io[1]):
         try:
             w.result()
         except OSError:
             pass
     with pytest.raises(OSError, match="disk full"):
         c._emit(str(tmp_path / "next.png"), np.zeros((2, 2, 3), np.uint8))
-    c._writer.shutdown(wait=True)
+    c._io[0].shutdown(wait=True)
