@@ -3,7 +3,8 @@ mapped one-to-one onto ``Cropper``; ``-c/--config`` JSON supplies defaults; nega
 thresholds mean "disabled" (None).  ``python -m face_crop_plus_amd -i DIR``.
 
 Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node N -m face_crop_plus_amd ...``;
-each rank takes every N-th file batch (face_crop_plus_amd/dist.py).
+rank 0 alone reads (or downloads) the checkpoints and broadcasts them over RCCL (weights.load_state_dict), then
+each rank takes every N-th file batch (face_crop_plus_amd/dist.py) — no data-path collective.
 """
 from __future__ import annotations
 
@@ -76,7 +77,8 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        # RCCL ("nccl" IS RCCL on ROCm), one rank per GPU; FCP_DIST_BACKEND=gloo only for ranks that share a device (tests)
+        dist.init_process_group(os.environ.get("FCP_DIST_BACKEND", "nccl"))
         dist.barrier()                                  # rank 0 has finished renaming / copying
     from .cropper import Cropper
     cropper = Cropper(**kwargs)

@@ -46,7 +46,7 @@ class BiSeNet:
             raise RuntimeError("face_crop_plus_amd runs on an AMD GPU only; there is no CPU fallback")
         N.lib()
         self.device = device
-        sd = load_state_dict("bisenet", weights)
+        sd = load_state_dict("bisenet", weights, device=device)
         with torch.cuda.device(device), E.default_precision(precision):
             self._p = self._pack(sd, device)
         self.precision = E.resolve_precision(precision)

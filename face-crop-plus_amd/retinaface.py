@@ -62,7 +62,7 @@ class RetinaFace:
                                "there is no CPU fallback")
         N.lib()  # fail loudly now if the extension is missing
         self.device = device
-        sd = load_state_dict("retinaface", weights)
+        sd = load_state_dict("retinaface", weights, device=device)
         with torch.cuda.device(device), E.default_precision(precision):
             self._p = self._pack(sd, device)
         self.precision = E.resolve_precision(precision)

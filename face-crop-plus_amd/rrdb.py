@@ -41,7 +41,7 @@ class RRDBNet:
             raise RuntimeError("face_crop_plus_amd runs on an AMD GPU only; there is no CPU fallback")
         N.lib()
         self.device = device
-        sd = load_state_dict("rrdb", weights)
+        sd = load_state_dict("rrdb", weights, device=device)
         with torch.cuda.device(device), E.default_precision(precision):
             pc = lambda k, prec=None: E.pack_conv(sd[k + ".weight"], sd[k + ".bias"], None, 1, 1, device,
                                                   precision=prec)

@@ -229,7 +229,46 @@ def _fetch_checkpoint(model: str):
     return torch.hub.load_state_dict_from_url(URL_ROOT + WEIGHTS_FILENAMES[model], map_location="cpu", progress=False)
 
 
-def load_state_dict(model: str, source=None, seed: int = 0):
+def load_state_dict(model: str, source=None, seed: int = 0, device=None):
+    """What the model objects call.  Single process (or ``source`` already a state dict in memory): ``load_local``.
+    Inside an initialised ``torch.distributed`` group of more than one rank (north_star: "RCCL broadcast of weights +
+    per-rank independent batches"): ONLY rank 0 resolves ``source`` — reads the checkpoint, or downloads it — and its
+    tensors reach the other ranks as one flat broadcast (``dist.broadcast_state_dict``, RCCL when the group's backend is
+    "nccl", on ``device``); ranks > 0 never touch the checkpoint directory or the network.  A failure on rank 0 is
+    raised on every rank (nobody is left waiting in the collective).  ``FCP_BROADCAST_WEIGHTS=0`` restores per-rank
+    loading."""
+    from . import dist as D
+    if isinstance(source, dict) or not D.is_dist() or os.environ.get("FCP_BROADCAST_WEIGHTS", "1") == "0":
+        return load_local(model, source, seed)
+    import torch
+    import torch.distributed as dist
+    rank, world = D.rank_world()
+    if world == 1:
+        return load_local(model, source, seed)
+    sd, err = None, None
+    if rank == 0:
+        try:
+            sd = load_local(model, source, seed)
+        except Exception as e:                       # noqa: BLE001 - reported on every rank below
+            err = f"{type(e).__name__}: {e}"
+    status = [err]
+    dist.broadcast_object_list(status, src=0)
+    if status[0] is not None:
+        raise RuntimeError(f"{model}: rank 0 could not load the weights it was to broadcast: {status[0]}")
+    names = [(n, tuple(shp)) for n, shp, _ in SPECS[model]()]
+    if rank == 0:
+        sd = {n: (sd[n] if torch.is_tensor(sd[n]) else torch.as_tensor(sd[n])) for n, _ in names}
+    else:                                            # same keys and shapes everywhere: the spec is the skeleton
+        sd = {n: (torch.zeros(shp, dtype=torch.float32) if not n.endswith("num_batches_tracked") else torch.tensor(0))
+              for n, shp in names}
+    if device is None and dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    elif dist.get_backend() != "nccl":
+        device = None                                # gloo (CPU tests; two ranks sharing one GPU): host tensors
+    return _validated(model, D.broadcast_state_dict(sd, device))
+
+
+def load_local(model: str, source=None, seed: int = 0):
     """``source``: a state dict, a ``.pth`` path, the string ``"generated"`` (the seeded random-init generator:
     an explicit opt-in for tests / benchmarks — its detections are meaningless), or None.
 

@@ -102,3 +102,45 @@ def test_rccl_world1_broadcast_and_reduce(tmp_path, device):
     mp.spawn(_rccl_worker, args=(_free_port(), str(out)), nprocs=1, join=True)
     same, s, m, backend = out.read_text().split()
     assert same == "1" and float(s) == 41.0 and float(m) == 7.5 and backend == "nccl"
+
+
+def _cli_worker(rank, world, port, src, out, ckpt):
+    """`python -m face_crop_plus_amd` under a launcher: rank 0 alone reads the checkpoint, everybody crops."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", FCP_DIST_BACKEND="gloo", FCP_OFFLINE="1",
+                      FCP_WEIGHTS_DIR=ckpt if rank == 0 else os.path.join(out, "nowhere"), TORCH_HOME=os.path.join(out, "th"))
+    os.environ.pop("FCP_WEIGHTS", None)
+    from face_crop_plus_amd import weights as W
+    touched = []
+    if rank != 0:
+        W.find_checkpoint = lambda m: touched.append(m)
+        torch.load = lambda *a, **k: touched.append(a)
+    from face_crop_plus_amd.__main__ import main
+    main(["-i", src, "-o", os.path.join(out, f"rank{rank}"), "-s", "64", "-r", "160", "-st", "all", "-dt", "0.55", "-b", "2"])
+    with open(os.path.join(out, f"touched{rank}.txt"), "w") as f:
+        f.write(str(len(touched)))
+
+
+def test_cli_two_ranks_rank0_loads_and_broadcasts(tmp_path, device):
+    from PIL import Image
+    from face_crop_plus_amd import Cropper, weights as W
+    src, ckpt, out = tmp_path / "src", tmp_path / "ckpt", tmp_path / "out"
+    for d in (src, ckpt, out):
+        d.mkdir()
+    rng = np.random.default_rng(10)
+    for i in range(7):
+        Image.fromarray(rng.integers(0, 256, (140, 150, 3), dtype=np.uint8)).save(src / f"g{i}.png")
+    sd = W.generate_state_dict("retinaface")
+    torch.save(sd, ckpt / "retinaface_detector.pth")
+    single = tmp_path / "single"
+    Cropper(**dict(KW, weights={"retinaface": sd})).process_dir(str(src), str(single), desc=None)
+    ref = {f: (single / f).read_bytes() for f in sorted(os.listdir(single))}
+    mp.spawn(_cli_worker, args=(2, _free_port(), str(src), str(out), str(ckpt)), nprocs=2, join=True)
+    got = {}
+    for r in (0, 1):
+        d = out / f"rank{r}"
+        for f in (sorted(os.listdir(d)) if d.is_dir() else []):
+            assert f not in got
+            got[f] = (d / f).read_bytes()
+    assert got == ref and len(ref) > 4
+    assert (out / "touched1.txt").read_text() == "0", "rank 1 looked for a checkpoint"
