@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_f32p = C.c_void_p
 _lib = None
@@ -61,6 +61,7 @@ SIGNATURES = {
     "fcp_stem7x7s2_relu_pool_conv1_u8": [_P, _I, _I, _I, C.POINTER(C.c_int32), _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "fcp_f32_to_split32": [_P, _P, _L, _I, _P],
     "fcp_split32_to_f32": [_P, _P, _L, _I, _P],
+    "fcp_absmax_nhwc": [_P, _L, _I, _I, _I, _P, _P],
     "fcp_retina_decode": [_P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "fcp_retina_nms_select": [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
     "fcp_retina_gather_faces": [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P],

@@ -179,7 +179,51 @@ inline int grid_for(long work_items, int block) {
   return (int)g;
 }
 
+// max |x| over a channel-slice view (range guard of the fp16x3 path): one lane per 8 channels of a pixel, wave
+// reduction, one atomicMax per wave on the bit pattern (non-negative floats order like their bits); NaN counts as +inf.
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long npix, int c, int ld, int fmt,
+                                                     unsigned* __restrict__ out) {
+  const int c8 = c >> 3;
+  const long total = npix * c8;
+  const long stride = (long)gridDim.x * blockDim.x;
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long px = i / c8;
+    const int ch = (int)(i - px * c8) << 3;
+    float v[8];
+    if (fmt == 1) {
+      const char* base = reinterpret_cast<const char*>(x + px * ld) + split_chan_off(ch);
+      join8(*reinterpret_cast<const u32x4_t*>(base), *reinterpret_cast<const u32x4_t*>(base + 64), v);
+    } else {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(x + px * ld + ch), b = *reinterpret_cast<const f32x4*>(x + px * ld + ch + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float a = v[k] != v[k] ? __builtin_inff() : __builtin_fabsf(v[k]);
+      m = a > m ? a : m;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(m, off, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+
 }  // namespace
+
+extern "C" int fcp_absmax_nhwc(const float* x, int64_t npix, int c, int ld, int fmt, float* out_max, fcp_stream_t stream) {
+  FCP_REQUIRE(x && out_max && npix > 0 && c > 0 && c % 8 == 0 && ld >= c && ld % 4 == 0 && ((uintptr_t)x & 15) == 0,
+              "absmax: bad arguments (c %% 8 == 0, 16-byte aligned view)");
+  FCP_REQUIRE(fmt == 0 || (fmt == 1 && c % 32 == 0 && ld % 32 == 0 && ((uintptr_t)x & 127) == 0),
+              "absmax: split32 views are 32-channel aligned");
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(npix * (c / 8), 256)), dim3(256), 0, (hipStream_t)stream, x, (long)npix,
+                     c, ld, fmt, reinterpret_cast<unsigned*>(out_max));
+  FCP_LAUNCH_OK();
+  return 0;
+}
 
 extern "C" int fcp_u8_to_nhwc4_f32(const uint8_t* in, float* out, int64_t npix,
                                    const float* sub_host, float div, fcp_stream_t stream) {

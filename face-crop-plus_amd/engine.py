@@ -220,6 +220,84 @@ class Autotune:
     enabled = os.environ.get("FCP_AUTOTUNE", "1") != "0"
     cache: dict = {}
     _lock = threading.Lock()     # process_dir's GPU workers share the cache: one tuner at a time
+    # Picks persist on disk, keyed by (device name, CU count, ABI version) + shape: a second start skips the timing
+    # launches.  Read order: the table shipped in face-crop-plus_amd/tuned/ (picks measured on an MI355X by
+    # tools/dump_autotune.py), then the user's file ($FCP_TUNE_CACHE, default ~/.cache/face_crop_plus_amd/autotune.json;
+    # "0" = no disk cache at all), which also receives every new pick.  Every candidate returns the same bits, so a
+    # stale pick can only cost speed; one that is no longer among a shape's candidates is ignored.
+    _disk_loaded = False
+    _disk_section = None         # "<device name>|<CUs>|abi<N>"
+    _disk_dirty = False
+
+    @classmethod
+    def _user_path(cls):
+        p = os.environ.get("FCP_TUNE_CACHE")
+        if p == "0":
+            return None
+        return p or os.path.join(os.path.expanduser("~"), ".cache", "face_crop_plus_amd", "autotune.json")
+
+    @classmethod
+    def section(cls):
+        if cls._disk_section is None:
+            prop = torch.cuda.get_device_properties(torch.cuda.current_device())
+            cls._disk_section = f"{prop.name}|{prop.multi_processor_count}|abi{N.ABI_VERSION}"
+        return cls._disk_section
+
+    @classmethod
+    def ensure_loaded(cls):
+        """Merge the shipped and the user's tables into ``cache`` (once per process; in-process picks win)."""
+        if cls._disk_loaded:
+            return
+        with cls._lock:
+            if cls._disk_loaded:
+                return
+            cls._disk_loaded = True
+            if os.environ.get("FCP_TUNE_CACHE") == "0":
+                return
+            import ast
+            import json
+            shipped = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned")
+            files = sorted(os.path.join(shipped, f) for f in os.listdir(shipped) if f.endswith(".json")) if os.path.isdir(shipped) else []
+            if cls._user_path() and os.path.isfile(cls._user_path()):
+                files.append(cls._user_path())
+            try:
+                sec = cls.section()
+            except Exception:                                # no GPU: nothing to key on
+                return
+            for path in files:
+                try:
+                    with open(path) as f:
+                        table = json.load(f).get(sec, {})
+                    for k, v in table.items():
+                        cls.cache.setdefault(ast.literal_eval(k), tuple(v))
+                except Exception as e:                       # a damaged table costs a re-tune, never a failure
+                    import warnings
+                    warnings.warn(f"autotune table {path} ignored: {type(e).__name__}: {e}")
+
+    @classmethod
+    def save(cls, path: str | None = None):
+        """Write this process's picks into the user's table (merged with what the file holds for other devices / shapes)."""
+        path = path or cls._user_path()
+        if path is None:
+            return None
+        import json
+        with cls._lock:
+            table = {}
+            try:
+                with open(path) as f:
+                    table = json.load(f)
+            except Exception:
+                pass
+            sec = table.setdefault(cls.section(), {})
+            for k, v in cls.cache.items():
+                sec[repr(k)] = list(v)
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "w") as f:
+                json.dump(table, f, indent=0, sort_keys=True)
+            os.replace(tmp, path)
+            cls._disk_dirty = False
+        return path
 
     @classmethod
     def pick(cls, key, candidates, launch):
@@ -253,7 +331,13 @@ class Autotune:
             if os.environ.get("FCP_AUTOTUNE_LOG"):
                 print("autotune", key, {str(c): round(t * 1e3, 1) for c, t in zip(candidates, times)}, "->", best, flush=True)
             cls.cache[key] = best
-            return best
+            cls._disk_dirty = True
+        if os.environ.get("FCP_TUNE_CACHE") != "0":
+            try:
+                cls.save()
+            except OSError:                                  # read-only home, full disk: tuning still works in-process
+                pass
+        return best
 
 
 class ConvStats:
@@ -268,6 +352,53 @@ class ConvStats:
         cls.flops, cls.launches = 0, 0
         if cls.timing is not None:
             cls.timing = []
+
+
+class RangeMonitor:
+    """Range guard of the fp16x3 path.  binary16 hi parts saturate at 65504 and the split silently loses its lo part
+    below 2^-14; the generated weights keep activations O(1-100), a real checkpoint has never been through this code
+    (no network in the build container).  While a monitor is active every conv / chain / stem launch is followed by one
+    ``fcp_absmax_nhwc`` launch on its output view; ``report()`` returns [(label, max |x|)] in launch order."""
+    active = None            # the monitor launches report to (one at a time: a diagnostic, not a data-path feature)
+    LIMIT = 32768.0          # 2^15: one binade of headroom below binary16's largest finite value
+
+    def __init__(self):
+        self.rows = []       # (label, device scalar)
+
+    def __enter__(self):
+        assert RangeMonitor.active is None, "RangeMonitor is not re-entrant"
+        RangeMonitor.active = self
+        return self
+
+    def __exit__(self, *exc):
+        RangeMonitor.active = None
+
+    def see(self, label: str, t: Act):
+        m = torch.zeros((), dtype=torch.float32, device=t.buf.device)
+        N.check(N.lib().fcp_absmax_nhwc(t.ptr(), t.n * t.h * t.w, t.c, t.ld, t.fmt, N.ptr(m), N.stream_ptr()), "fcp_absmax_nhwc")
+        self.rows.append((label, m))
+
+    def report(self):
+        return [(label, float(m.item())) for label, m in self.rows]
+
+    def check(self, what: str):
+        rep = self.report()
+        bad = [(label, v) for label, v in rep if not v < self.LIMIT]
+        if bad:
+            worst = max(bad, key=lambda r: r[1])
+            raise FloatingPointError(
+                f"{what}: activations leave the range of the fp16x3 (split binary16) conv path: |x| reaches {worst[1]:.4g} "
+                f"after '{worst[0]}' ({len(bad)} of {len(rep)} launches at or above 2^15 = {self.LIMIT:.0f}; binary16 "
+                f"saturates at 65504).  Load the model with precision='f32' (exact fp32 MFMA path) for these weights.")
+        return rep
+
+
+def _monitor(label, *outs):
+    mon = RangeMonitor.active
+    if mon is not None:
+        for i, t in enumerate(outs):
+            if t is not None and t.c % 8 == 0:
+                mon.see(label if i == 0 else f"{label} [output {i}]", t)
 
 
 def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1.0,
@@ -329,10 +460,25 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     # (it also runs 33 .. 64 filters, tile (1, 64): 586 vs 600 us alone on RRDB's conv5, nothing end to end: not offered)
     wide_ok = (pc.precision == 1 and x.fmt == 1 and not pc.cin4 and (pc.kh, pc.kw, pc.stride, pc.pad) == (3, 3, 1, 1)
                and pc.cout % 8 == 0 and pc.cin % 64 == 0 and x2 is None and 64 < pc.cout <= 128 and res1 is None and res2 is None)
+    if tile_n is None and tile_m is None and (pc.cout > 64 or halo_ok):
+        Autotune.ensure_loaded()
     if tile_n is None and tile_m is None and (pc.cout > 64 or halo_ok) and (Autotune.enabled or Autotune.cache):
         key = (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, m, int(in_up2), res1 is not None, res2 is not None,
                pc.precision, x.fmt, out.fmt, None if x2 is None else (x2.c, x2_stride), d.cu_budget)
+        cands = [(128, 128), (128, 64)]
+        if halo_ok:
+            cands = ([(128, 32)] if pc.cout <= 32 else []) + [(128, 64), (1, 32)]
+        if wide_ok and HALO_WIDE:
+            cands = cands + [(1, 128)]
+        if big_ok and BIG_TILES:
+            big = [(256, 128)] + ([(256, 256)] if pc.cout >= 256 else []) + ([(256, 192)] if 128 < pc.cout <= 192 else [])
+            cands += big
+            if BALANCE_TAIL:      # the same tiles with the last dispatch round cut into shorter M-tiles (same bits)
+                cands += [(tm, tn, N.CONV_BALANCE_TAIL) for tm, tn in big]
         best = Autotune.cache.get(key)          # a tuned shape keeps its tile after tuning is switched off
+        if best is not None and tuple(best) not in cands:
+            Autotune.cache.pop(key, None)       # a pick from an older table that this build no longer offers
+            best = None
         if best is None and Autotune.enabled:
             # Tuning launches the op several times.  An op whose output aliases one of its inputs (RRDB's last dense-block
             # conv writes the buffer its second residual is read from) is not idempotent: its trial launches write a
@@ -354,16 +500,6 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
                     d.out, d.out_ld = N.ptr(scratch), out.c
                 N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
                 d.out, d.out_ld = real_out, real_ld
-            cands = [(128, 128), (128, 64)]
-            if halo_ok:
-                cands = ([(128, 32)] if pc.cout <= 32 else []) + [(128, 64), (1, 32)]
-            if wide_ok and HALO_WIDE:
-                cands = cands + [(1, 128)]
-            if big_ok and BIG_TILES:
-                big = [(256, 128)] + ([(256, 256)] if pc.cout >= 256 else []) + ([(256, 192)] if 128 < pc.cout <= 192 else [])
-                cands += big
-                if BALANCE_TAIL:      # the same tiles with the last dispatch round cut into shorter M-tiles (same bits)
-                    cands += [(tm, tn, N.CONV_BALANCE_TAIL) for tm, tn in big]
             best = Autotune.pick(key, cands, _launch)
             d.flags = base_flags
         if best is not None:
@@ -394,6 +530,8 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     if ConvStats.enabled:
         ConvStats.flops += pc.flops_per_pixel * m
         ConvStats.launches += 1
+    if RangeMonitor.active is not None:
+        _monitor(f"conv {pc.kh}x{pc.kw} s{pc.stride} {pc.cin}->{pc.cout} @{oh}x{ow}", out)
     return out
 
 
@@ -469,6 +607,8 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
     if ConvStats.enabled:
         ConvStats.flops += flops
         ConvStats.launches += 1
+    if RangeMonitor.active is not None:
+        _monitor(f"chain {'3x3 ' if pc2 is not None else ''}{pc3.cin}->{pc3.cout}->{pc1n.cout} @{t1.h}x{t1.w}", out, t1n)
     return out, t1n
 
 
@@ -571,6 +711,8 @@ def stem_relu_pool_u8(ps: PackedStem, images_u8: torch.Tensor, out: Act | None =
     if ConvStats.enabled:
         ConvStats.flops += flops
         ConvStats.launches += 1
+    if RangeMonitor.active is not None:
+        _monitor(f"stem 7x7 s2 + pool @{hp}x{wp}", out, t1)
     return out if conv1 is None else (out, t1)
 
 

@@ -66,7 +66,62 @@ class RetinaFace:
         with torch.cuda.device(device), E.default_precision(precision):
             self._p = self._pack(sd, device)
         self.precision = E.resolve_precision(precision)
+        # Range / accuracy guard of the fp16x3 path (``selfcheck``): FCP_SELFCHECK=1 always, 0 never; by default ("auto")
+        # whenever the weights come from a checkpoint — a file, the hub cache or a download — i.e. are not this package's
+        # own generated ones or a state dict the caller built in memory.
+        mode = os.environ.get("FCP_SELFCHECK", "auto")
+        from_checkpoint = weights is None or (isinstance(weights, str) and weights != "generated")
+        if self.precision == 1 and (mode == "1" or (mode == "auto" and from_checkpoint)):
+            self.selfcheck(sd)
         return self
+
+    @torch.no_grad()
+    def selfcheck(self, sd=None, images_u8: torch.Tensor | None = None, rel_tol: float = 1e-4):
+        """Guard of the split-binary16 conv path against weights it cannot represent (the reference computes in fp32 and
+        takes any checkpoint, _layers.py:16-35; here binary16 hi parts saturate at 65504).  Runs a small calibration batch
+        (noise, white, black, a ramp — or ``images_u8``) through the network with a max-|x| reduction behind every
+        launch and raises ``FloatingPointError`` naming the launch if any activation reaches 2^15; with ``sd`` (the
+        state dict) it also packs an exact-fp32 twin and requires the fused head maps of the two paths to agree within
+        ``rel_tol`` of the map's largest value.  Returns (and keeps in ``self.selfcheck_report``) the per-launch maxima
+        and the head differences."""
+        if self.precision != 1:
+            self.selfcheck_report = {"skipped": "exact-fp32 path: nothing to guard"}
+            return self.selfcheck_report
+        dev = self.device
+        with torch.cuda.device(dev):
+            if images_u8 is None:
+                g = torch.Generator(device="cpu").manual_seed(20260928)
+                s = 256
+                ramp = (torch.arange(s)[:, None] + torch.arange(s)[None, :]).clamp(max=255).to(torch.uint8)
+                images_u8 = torch.stack([torch.randint(0, 256, (s, s, 3), generator=g, dtype=torch.uint8),
+                                         torch.full((s, s, 3), 255, dtype=torch.uint8), torch.zeros((s, s, 3), dtype=torch.uint8),
+                                         ramp[..., None].expand(s, s, 3).contiguous()]).to(dev)
+            images_u8 = images_u8.to(dev).contiguous()
+            tuning, E.Autotune.enabled = E.Autotune.enabled, False        # a check must not spend time tuning tiles
+            try:
+                with E.RangeMonitor() as mon:
+                    heads = self.forward_heads(None, images_u8) if "stem_fused" in self._p and self.fused_stem else \
+                        self.forward_heads(E.u8_to_nhwc4(images_u8, sub=(123.0, 117.0, 104.0)))
+                rep = {"launch_absmax": mon.check("RetinaFace"), "limit": E.RangeMonitor.LIMIT, "head_rel_diff": None}
+                if sd is not None:
+                    twin = RetinaFace(self.strategy, self.vis_threshold)
+                    twin.device, twin.precision = dev, 0
+                    with E.default_precision("f32"):
+                        twin._p = self._pack(sd, dev)
+                    ref = twin.forward_heads(E.u8_to_nhwc4(images_u8, sub=(123.0, 117.0, 104.0)))
+                    diffs = []
+                    for a, b in zip(heads, ref):
+                        scale = float(b.buf.abs().max().item())
+                        diffs.append(float((a.buf - b.buf).abs().max().item()) / max(scale, 1e-30))
+                    rep["head_rel_diff"] = diffs
+                    if not max(diffs) <= rel_tol:
+                        raise FloatingPointError(
+                            f"RetinaFace: the fp16x3 path and the exact-fp32 path disagree on the head maps by {max(diffs):.3g} "
+                            f"of their largest value (tolerance {rel_tol:g}) with these weights; load with precision='f32'.")
+            finally:
+                E.Autotune.enabled = tuning
+        self.selfcheck_report = rep
+        return rep
 
     @staticmethod
     def _pack(sd, dev):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 11
+#define FCP_ABI_VERSION 12
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -208,6 +208,11 @@ int fcp_stem7x7s2_relu_pool_conv1_u8(const uint8_t* images, int n, int h, int w,
 /* Format converters between fp32 NHWC and split32 (npix pixels of c channels, c % 32 == 0). */
 int fcp_f32_to_split32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream);
 int fcp_split32_to_f32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream);
+/* Range guard of the fp16x3 path (no reference counterpart: the reference computes in fp32, _layers.py:16-35 hands it
+ * arbitrary checkpoints): *out_max = max(*out_max, max |x|) over a channel-slice view of npix pixels x c channels
+ * (pixel pitch ld elements; fmt 0 fp32 / 1 split32; c % 8 == 0), NaN counted as +inf.  *out_max must be initialised
+ * (>= 0) by the caller; the update is an atomic max on the device. */
+int fcp_absmax_nhwc(const float* x, int64_t npix, int c, int ld, int fmt, float* out_max, fcp_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * RetinaFace post-processing.

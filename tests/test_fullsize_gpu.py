@@ -57,6 +57,34 @@ def test_configs_batch_independence_and_determinism(batch, size, det, device):
         assert (np.diff(sc[kp]) <= 0).all()                                  # kept boxes come in score order
 
 
+@pytest.mark.parametrize("batch,size,sample", [(64, 640, (0, 21, 42, 63)), (32, 1024, (0, 31))])
+def test_c2_c3_sample_vs_oracle(batch, size, sample, det, device):
+    """The benchmark workloads themselves (BASELINE configs[1] / the north-star geometry, seed-1234 batch as in
+    bench.py) against the oracle, on a sample of their images: the GPU results of the FULL batch at those images must
+    give the oracle's indices, landmarks within 1e-3 px (north_star), and crops byte-equal to the oracle's estimate +
+    warp of the GPU's landmarks (retinaface.py:449-470, cropper.py:514-547)."""
+    from face_crop_plus_amd import align, weights
+    from face_crop_plus_amd.cropper import landmarks_target
+    from oracle import retinaface_ref as R, align_ref as A
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    imgs_h = torch.randint(0, 256, (batch, size, size, 3), generator=g, dtype=torch.uint8)
+    imgs = imgs_h.to(device)
+    lm, idx, res = _detect(det, imgs)
+    tgt = landmarks_target((256, 256), 0.65)
+    crops, ok, _ = align.crop_align(imgs, res["img_idx"], res["landmarks"], tgt, (256, 256), 0)
+    crops, ok = crops.cpu().numpy(), ok.cpu().numpy()
+    sd = weights.generate_state_dict("retinaface")
+    sub = imgs_h[list(sample)]
+    lm_ref, idx_ref = R.predict(sub.permute(0, 3, 1, 2).float(), sd, "largest", 0.6)
+    assert idx_ref == list(range(len(sample)))                              # one face per sampled image
+    rows = [int(np.nonzero(idx == i)[0][0]) for i in sample]
+    assert all((idx == i).sum() == 1 for i in sample)
+    err = np.abs(lm[rows] - lm_ref).max()
+    assert err < 1e-3, f"landmarks {err} px from the oracle"
+    ref_crops = A.crop_align(sub.numpy(), None, idx_ref, lm[rows], tgt, (256, 256), "constant")
+    assert ok[rows].all() and np.array_equal(crops[rows], ref_crops)
+
+
 def test_full_size_crops_match_single_image_warp(det, device):
     from face_crop_plus_amd import align
     from face_crop_plus_amd.cropper import landmarks_target
