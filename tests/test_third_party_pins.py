@@ -20,7 +20,10 @@ def _fixture(name):
     if not os.path.isfile(path):
         pytest.skip(f"tests/golden/{name} is absent (no cv2 / torchvision in the build container): parity of this row stays "
                     f"unpinned; {HOW}")
-    return np.load(path)
+    z = np.load(path)
+    versions = {k: str(z[k]) for k in z.files if k.endswith("_version")}
+    print(f"tests/golden/{name}: generated with {versions}")                 # shown with `pytest -s` / `-rP`
+    return z
 
 
 # ------------------------------------------------------------------------------------------- a13: estimators
