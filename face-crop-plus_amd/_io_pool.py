@@ -1,0 +1,232 @@
+"""Decode / encode worker PROCESSES behind ``Cropper.process_dir`` (reference ``utils.py:228-271``
+read side, ``cropper.py:554-609`` write side).
+
+Round 3 ran Pillow on an I/O thread pool: 1300-1440 images/s end to end against 2600 for the device path alone — the
+rest was Python under the GIL (array conversion, EXIF handling, encoder set-up, executor bookkeeping).  Here every I/O
+thread of the executor owns ONE forked worker process and does a blocking request / reply with it, so the thread
+architecture of ``process_dir`` (prefetch depth, back-pressure, error surfacing, file naming, warn-and-skip) is
+unchanged while the CPU-heavy part runs outside the parent's interpreter:
+
+* read:  the worker decodes the file (``utils.read_image``: same EXIF / RGB rules) into its own ring of shared
+  memory (an anonymous ``MAP_SHARED`` mapping created before the fork: no /dev/shm, no pickling of pixels) and replies
+  ``(offset, h, w)``; the parent wraps the region as a numpy view and gives it back (``release``) once the batch that
+  used it is done.  A worker NEVER waits for ring space — an image that does not fit right now travels through the pipe
+  instead — so a ring that is too small for a batch of 4K frames costs speed, not progress.
+* write: the parent sends the crop's bytes through the pipe (``send_bytes``: a syscall, GIL released), the worker
+  encodes with ``utils.write_image`` (same encoder table, same warn-and-skip) and replies.
+
+Workers are forked (like ``torch.utils.data.DataLoader``'s): they never touch the GPU runtime, only numpy + Pillow, and
+leave through ``os._exit``.  ``FCP_IO_PROCESSES=0`` keeps everything on threads (the round-3 behaviour).
+"""
+from __future__ import annotations
+
+import mmap
+import os
+import threading
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+
+RING_MB = int(os.environ.get("FCP_IO_RING_MB", "128"))
+
+
+def _worker(conn, ring: mmap.mmap | None, ring_bytes: int, ctl: mmap.mmap, slot: int, inherited):
+    """Child process: serve requests until the pipe closes.  Never returns (``os._exit``)."""
+    try:
+        for c in inherited:                                 # parent-side pipe ends of the workers forked before this one:
+            try:                                            # held open here they would keep those workers from ever
+                c.close()                                   # seeing EOF when the parent goes away
+            except OSError:
+                pass
+        from .utils import read_image, write_image
+        consumed = np.frombuffer(ctl, dtype=np.int64)      # consumed[slot]: bytes the parent has given back (monotonic)
+        produced = 0                                        # bytes handed out so far, incl. skipped ring tails (monotonic)
+        while True:
+            try:
+                msg = conn.recv()
+            except (EOFError, OSError):
+                break
+            if msg is None:
+                break
+            kind = msg[0]
+            try:
+                with warnings.catch_warnings(record=True) as caught:
+                    warnings.simplefilter("always")
+                    if kind == "read":
+                        img = read_image(msg[1])
+                        notes = [str(w.message) for w in caught]
+                        if img is None:
+                            conn.send(("none", notes))
+                            continue
+                        need = img.nbytes
+                        pos = produced % ring_bytes if ring_bytes else 0
+                        skip = ring_bytes - pos if ring_bytes and pos + need > ring_bytes else 0
+                        if ring_bytes and need <= ring_bytes and produced + skip + need - int(consumed[slot]) <= ring_bytes:
+                            off = (pos + skip) % ring_bytes
+                            np.frombuffer(ring, dtype=np.uint8, count=need, offset=off)[:] = img.reshape(-1)
+                            produced += skip + need
+                            conn.send(("ring", off, img.shape, skip + need, notes))
+                        else:                               # no room right now: through the pipe, never wait
+                            conn.send(("pipe", img.shape, notes))
+                            conn.send_bytes(memoryview(np.ascontiguousarray(img)).cast("B"))
+                    elif kind == "write":
+                        _, path, shape = msg
+                        pixels = np.frombuffer(conn.recv_bytes(), dtype=np.uint8).reshape(shape)
+                        ok = write_image(path, pixels)
+                        conn.send(("done", bool(ok), [str(w.message) for w in caught]))
+                    else:
+                        conn.send(("error", f"unknown request {kind!r}"))
+            except Exception as e:                          # noqa: BLE001 - reported to the parent, which re-raises
+                conn.send(("error", f"{type(e).__name__}: {e}"))
+    finally:
+        os._exit(0)                                         # no atexit handlers / destructors of the forked parent state
+
+
+class _Worker:
+    """Parent-side handle of one worker process; used by exactly one I/O thread at a time."""
+
+    def __init__(self, ctx, ctl, slot, ring_bytes, earlier=()):
+        self.ring_bytes = ring_bytes
+        self.ring = mmap.mmap(-1, ring_bytes) if ring_bytes else None       # anonymous + shared: inherited by the fork
+        self.conn, child = ctx.Pipe(duplex=True)
+        self.proc = ctx.Process(target=_worker, args=(child, self.ring, ring_bytes, ctl, slot,
+                                                      [w.conn for w in earlier] + [self.conn]), daemon=True)
+        self.proc.start()
+        child.close()
+        self.slot, self.ctl = slot, np.frombuffer(ctl, dtype=np.int64)
+        self.lock = threading.Lock()
+        self.regions = OrderedDict()                 # seq -> [bytes, released]; the released PREFIX is given back
+        self.seq = 0
+        self.given_back = 0
+
+    def _reply(self):
+        try:
+            rep = self.conn.recv()
+        except (EOFError, OSError) as e:
+            raise RuntimeError(f"I/O worker process {self.proc.pid} died ({type(e).__name__})") from e
+        if rep[0] == "error":
+            raise RuntimeError(f"I/O worker: {rep[1]}")
+        return rep
+
+    def read(self, path):
+        """-> (RGB uint8 HWC array or None, release token or None).  Warnings of the decoder are re-issued here."""
+        self.conn.send(("read", path))
+        rep = self._reply()
+        for note in rep[-1]:
+            warnings.warn(note)
+        if rep[0] == "none":
+            return None, None
+        if rep[0] == "pipe":
+            buf = bytearray(int(np.prod(rep[1])))
+            self.conn.recv_bytes_into(buf)
+            return np.frombuffer(buf, dtype=np.uint8).reshape(rep[1]), None
+        _, off, shape, nbytes, _ = rep
+        arr = np.frombuffer(self.ring, dtype=np.uint8, count=int(np.prod(shape)), offset=off).reshape(shape)
+        with self.lock:
+            self.seq += 1
+            self.regions[self.seq] = [nbytes, False]
+            return arr, (self, self.seq)
+
+    def release(self, seq):
+        with self.lock:
+            self.regions[seq][1] = True
+            while self.regions:
+                first = next(iter(self.regions))
+                if not self.regions[first][1]:
+                    break
+                self.given_back += self.regions.pop(first)[0]
+            self.ctl[self.slot] = self.given_back    # one aligned 8-byte store: the worker only ever reads it
+
+    def write(self, path, pixels: np.ndarray) -> bool:
+        pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+        self.conn.send(("write", path, pixels.shape))
+        self.conn.send_bytes(memoryview(pixels).cast("B"))
+        rep = self._reply()
+        for note in rep[2]:
+            warnings.warn(note)
+        return rep[1]
+
+    def close(self):
+        try:
+            self.conn.send(None)
+        except (OSError, ValueError):
+            pass
+        self.proc.join(timeout=2)
+        if self.proc.is_alive():
+            self.proc.terminate()
+            self.proc.join(timeout=2)
+        self.conn.close()
+        if self.ring is not None:
+            try:
+                self.ring.close()
+            except BufferError:                      # a numpy view of a region is still alive somewhere: leave it to the GC
+                pass
+
+
+class IOProcesses:
+    """``readers`` decode workers (each with a ring) + ``writers`` encode workers; I/O threads borrow one each through
+    ``reader()`` / ``writer()`` (thread-local, so a worker's pipe is only ever used by one thread)."""
+
+    def __init__(self, readers: int, writers: int, ring_mb: int = RING_MB):
+        import multiprocessing as mp
+        ctx = mp.get_context("fork")
+        self._ctl = mmap.mmap(-1, 8 * (readers + writers))
+        self._readers, self._writers = [], []
+        with warnings.catch_warnings():
+            # "os.fork() was called ... multi-threaded": true and intended, the children run numpy + Pillow only
+            warnings.simplefilter("ignore", DeprecationWarning)
+            for i in range(readers):
+                self._readers.append(_Worker(ctx, self._ctl, i, ring_mb << 20, self._readers))
+            for i in range(writers):
+                self._writers.append(_Worker(ctx, self._ctl, readers + i, 0, self._readers + self._writers))
+        self._lock = threading.Lock()
+        self.closed = False
+        self.begin()
+
+    @property
+    def readers(self):
+        return len(self._readers)
+
+    @property
+    def writers(self):
+        return len(self._writers)
+
+    def begin(self):
+        """Start of a ``process_dir`` run: its (new) I/O threads claim workers afresh."""
+        self._free_r, self._free_w = list(self._readers), list(self._writers)
+        self._tls = threading.local()
+
+    def _mine(self, name, free):
+        w = getattr(self._tls, name, None)
+        if w is None:
+            with self._lock:
+                if not free:
+                    raise RuntimeError("more I/O threads than worker processes")
+                w = free.pop()
+            setattr(self._tls, name, w)
+        return w
+
+    def read(self, path):
+        return self._mine("r", self._free_r).read(path)
+
+    def write(self, path, pixels):
+        return self._mine("w", self._free_w).write(path, pixels)
+
+    @staticmethod
+    def release(tokens):
+        for tok in tokens:
+            if tok is not None:
+                tok[0].release(tok[1])
+
+    def close(self):
+        if not self.closed:
+            self.closed = True
+            for w in self._readers + self._writers:
+                w.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                            # noqa: BLE001 - interpreter shutdown
+            pass

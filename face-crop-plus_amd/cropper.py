@@ -75,6 +75,11 @@ class Cropper:
         self.num_std_landmarks = 5
         # host I/O threads of process_dir (decode prefetch + asynchronous encode/write around the GPU workers)
         self.io_threads = max(2, min(16, (os.cpu_count() or 4) // 2))
+        # ... and, by default, one forked decode / encode worker PROCESS behind every I/O thread (_io_pool.py): the
+        # Pillow work leaves the parent's interpreter lock.  (readers, writers); None = sized from the host's cores;
+        # FCP_IO_PROCESSES=0 (or io_processes = (0, 0)) keeps decode / encode on the threads
+        self.io_processes = (0, 0) if os.environ.get("FCP_IO_PROCESSES", "1") == "0" else None
+        self._io_procs = None
         # set by process_dir as ONE tuple (executor the encoded files are written on, futures of the writes still in
         # flight, semaphore bounding them), so that a task of a failed run can never see a half-reset state
         self._io = None
@@ -192,10 +197,14 @@ class Cropper:
             write_image(path, pixels)
             return
         slots.acquire()
+        procs = getattr(self, "_io_procs_active", None)       # encode in the thread's worker process, or on the thread
 
         def task():
             try:
-                write_image(path, pixels)
+                if procs is not None:
+                    procs.write(path, pixels)
+                else:
+                    write_image(path, pixels)
             finally:
                 slots.release()
         with self._write_lock:
@@ -340,17 +349,29 @@ class Cropper:
         # and the output directory layout are exactly those of the synchronous `process_batch`.
         from concurrent.futures import ThreadPoolExecutor
         depth = max(2, 2 * self.num_processes)
-        io = ThreadPoolExecutor(max_workers=self.io_threads, thread_name_prefix="fcp-io")
+        procs = self._io_processes()
+        if procs is not None:
+            # one I/O thread per worker process (a thread only relays: request, blocking reply); decode and encode have
+            # their own executors so that a burst of reads can never starve the writes a batch needs to finish
+            procs.begin()
+            io = ThreadPoolExecutor(max_workers=procs.readers, thread_name_prefix="fcp-read")
+            wio = ThreadPoolExecutor(max_workers=procs.writers, thread_name_prefix="fcp-write")
+            read_one = procs.read
+        else:
+            io = wio = ThreadPoolExecutor(max_workers=self.io_threads, thread_name_prefix="fcp-io")
+            read_one = lambda path: (read_image(path), None)
+        self._io_procs_active = procs
         writes = []
-        self._io = (io, writes, BoundedSemaphore(self.MAX_PENDING_WRITES))
+        self._io = (wio, writes, BoundedSemaphore(self.MAX_PENDING_WRITES))
         # every file is its own decode task (a batch decoded by one thread would cap the pipeline at `depth` decoders)
         def submit_read(i):
-            return [io.submit(read_image, os.path.join(input_dir, f)) for f in file_batches[i]]
+            return [io.submit(read_one, os.path.join(input_dir, f)) for f in file_batches[i]]
 
         def collect_read(i, futs):
+            """-> images, surviving names, release tokens of the shared-memory regions the images live in."""
             decoded = [f.result() for f in futs]
-            ok = [k for k, im in enumerate(decoded) if im is not None]
-            return [decoded[k] for k in ok], np.array(file_batches[i])[ok]
+            ok = [k for k, (im, _) in enumerate(decoded) if im is not None]
+            return [decoded[k][0] for k in ok], np.array(file_batches[i])[ok], [tok for _, tok in decoded]
 
         reads = {i: submit_read(i) for i in range(min(depth, len(file_batches)))}
         lock = Lock()
@@ -363,18 +384,25 @@ class Cropper:
                 nxt = i + depth
                 if nxt < len(file_batches) and nxt not in reads:
                     reads[nxt] = submit_read(nxt)
-            images, names = collect_read(i, futs) if futs is not None else read_images(file_batches[i], input_dir)
-            if self.num_processes == 1:
-                return self._process_images(images, names, output_dir)
-            # one HIP stream per GPU worker: the batches of different workers overlap on the device (the tail of
-            # one kernel with the head of another; measured +4 % at two streams) instead of queueing on stream 0
-            if not hasattr(tls, "stream"):
-                with torch.cuda.device(self.device):
-                    tls.stream = torch.cuda.Stream()
-                    tls.stream.wait_stream(torch.cuda.default_stream())      # filters were uploaded there
-            with torch.cuda.device(self.device), torch.cuda.stream(tls.stream):
-                self._process_images(images, names, output_dir)
-                tls.stream.synchronize()
+            images, names, tokens = collect_read(i, futs) if futs is not None else (*read_images(file_batches[i], input_dir), [])
+            try:
+                if self.num_processes == 1:
+                    return self._process_images(images, names, output_dir)
+                # one HIP stream per GPU worker: the batches of different workers overlap on the device (the tail of
+                # one kernel with the head of another; measured +4 % at two streams) instead of queueing on stream 0
+                if not hasattr(tls, "stream"):
+                    with torch.cuda.device(self.device):
+                        tls.stream = torch.cuda.Stream()
+                        tls.stream.wait_stream(torch.cuda.default_stream())      # filters were uploaded there
+                with torch.cuda.device(self.device), torch.cuda.stream(tls.stream):
+                    self._process_images(images, names, output_dir)
+                    tls.stream.synchronize()
+            finally:
+                # the batch has been uploaded (build_batch copies into pinned staging and waits for the copy) and every
+                # host-side use of the decoded images is over: their ring regions go back to the decode workers
+                del images
+                if procs is not None:
+                    procs.release(tokens)
 
         try:
             with ThreadPool(self.num_processes) as pool:
@@ -390,4 +418,30 @@ class Cropper:
                 w.result()                       # surface encode / write errors
         finally:
             io.shutdown(wait=True)       # in-flight tasks still hold the semaphore / list: reset only afterwards
+            if wio is not io:
+                wio.shutdown(wait=True)
             self._io = None
+            self._io_procs_active = None
+
+    def _io_processes(self):
+        """The decode / encode worker processes of this Cropper (forked on first use, reused by later runs), or None
+        when they are switched off or cannot be had (no fork on this platform)."""
+        want = self.io_processes
+        if want is None:
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+            want = (max(2, min(16, cores * 5 // 8)), max(1, min(6, cores // 5)))
+        if min(want) <= 0:
+            return None
+        have = self._io_procs
+        if have is not None and not have.closed and (have.readers, have.writers) == tuple(want):
+            return have
+        if have is not None:
+            have.close()
+        try:
+            from ._io_pool import IOProcesses
+            self._io_procs = IOProcesses(*want)
+        except (ValueError, OSError) as e:           # no "fork" start method / no processes left: threads still work
+            import warnings
+            warnings.warn(f"decode / encode worker processes unavailable ({e}): using I/O threads")
+            self.io_processes, self._io_procs = (0, 0), None
+        return self._io_procs

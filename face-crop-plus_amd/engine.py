@@ -220,7 +220,7 @@ class Autotune:
     enabled = os.environ.get("FCP_AUTOTUNE", "1") != "0"
     cache: dict = {}
     _lock = threading.Lock()     # process_dir's GPU workers share the cache: one tuner at a time
-    # Picks persist on disk, keyed by (device name, CU count, ABI version) + shape: a second start skips the timing
+    # Picks persist on disk, keyed by (ISA name, CU count, ABI version) + shape: a second start skips the timing
     # launches.  Read order: the table shipped in face-crop-plus_amd/tuned/ (picks measured on an MI355X by
     # tools/dump_autotune.py), then the user's file ($FCP_TUNE_CACHE, default ~/.cache/face_crop_plus_amd/autotune.json;
     # "0" = no disk cache at all), which also receives every new pick.  Every candidate returns the same bits, so a
@@ -240,7 +240,10 @@ class Autotune:
     def section(cls):
         if cls._disk_section is None:
             prop = torch.cuda.get_device_properties(torch.cuda.current_device())
-            cls._disk_section = f"{prop.name}|{prop.multi_processor_count}|abi{N.ABI_VERSION}"
+            # the marketing name differs between boxes of one pool ("AMD Radeon Graphics" / "AMD Instinct MI355X"):
+            # the ISA name + CU count identify the part
+            arch = getattr(prop, "gcnArchName", prop.name).split(":")[0]
+            cls._disk_section = f"{arch}|{prop.multi_processor_count}|abi{N.ABI_VERSION}"
         return cls._disk_section
 
     @classmethod

@@ -10,7 +10,7 @@ def tuner(monkeypatch, tmp_path):
     monkeypatch.setenv("FCP_TUNE_CACHE", str(tmp_path / "tune.json"))
     monkeypatch.setattr(E.Autotune, "cache", {})
     monkeypatch.setattr(E.Autotune, "_disk_loaded", False)
-    monkeypatch.setattr(E.Autotune, "_disk_section", "AMD Instinct MI355X|256|abi0")
+    monkeypatch.setattr(E.Autotune, "_disk_section", "gfx950|256|abi0")
     return E.Autotune
 
 
@@ -20,7 +20,7 @@ def test_picks_round_trip_through_the_user_table(tuner, tmp_path, monkeypatch):
     tuner.cache.update({k1: (256, 256, 2), k2: (128, 64)})
     assert tuner.save() == str(tmp_path / "tune.json")
     table = json.loads((tmp_path / "tune.json").read_text())
-    assert list(table) == ["AMD Instinct MI355X|256|abi0"] and len(table["AMD Instinct MI355X|256|abi0"]) == 2
+    assert list(table) == ["gfx950|256|abi0"] and len(table["gfx950|256|abi0"]) == 2
     tuner.cache.clear()
     monkeypatch.setattr(tuner, "_disk_loaded", False)
     tuner.ensure_loaded()
@@ -28,13 +28,13 @@ def test_picks_round_trip_through_the_user_table(tuner, tmp_path, monkeypatch):
     # another device / ABI sees nothing of it, and keeps its own section when it saves
     tuner.cache.clear()
     monkeypatch.setattr(tuner, "_disk_loaded", False)
-    monkeypatch.setattr(tuner, "_disk_section", "AMD Instinct MI355X|256|abi1")
+    monkeypatch.setattr(tuner, "_disk_section", "gfx950|256|abi1")
     tuner.ensure_loaded()
     assert k1 not in tuner.cache
     tuner.cache[k1] = (128, 128)
     tuner.save()
     table = json.loads((tmp_path / "tune.json").read_text())
-    assert sorted(table) == ["AMD Instinct MI355X|256|abi0", "AMD Instinct MI355X|256|abi1"]
+    assert sorted(table) == ["gfx950|256|abi0", "gfx950|256|abi1"]
 
 
 def test_damaged_or_disabled_table_is_harmless(tuner, tmp_path, monkeypatch):

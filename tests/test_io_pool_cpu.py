@@ -1,0 +1,90 @@
+"""Decode / encode worker processes of process_dir (face-crop-plus_amd/_io_pool.py): host logic, no GPU."""
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+
+def _img(h, w, seed):
+    return np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+@pytest.fixture
+def pool():
+    from face_crop_plus_amd._io_pool import IOProcesses
+    p = IOProcesses(readers=2, writers=1, ring_mb=1)
+    yield p
+    p.close()
+
+
+def test_round_trip_ring_wrap_pipe_fallback_and_release(pool, tmp_path):
+    from PIL import Image
+    # 300 KB images against a 1 MiB ring: three fit, the fourth goes through the pipe until regions are released
+    imgs = [_img(320, 320, s) for s in range(8)]
+    for i, im in enumerate(imgs):
+        Image.fromarray(im).save(tmp_path / f"{i}.png")
+    got = [pool.read(str(tmp_path / f"{i}.png")) for i in range(5)]           # one thread = one worker
+    assert all(np.array_equal(g[0], imgs[i]) for i, g in enumerate(got))
+    in_ring = [tok is not None for _, tok in got]
+    assert in_ring == [True, True, True, False, False]
+    pool.release([tok for _, tok in got[1:3]])                                 # out of order: nothing is given back yet
+    more, tok = pool.read(str(tmp_path / "5.png"))
+    assert tok is None and np.array_equal(more, imgs[5])
+    pool.release([got[0][1]])                                                  # the prefix is complete: all three regions free
+    del got
+    for i in (6, 7, 0):                                                        # the ring wraps (tail skipped) and keeps going
+        arr, tok = pool.read(str(tmp_path / f"{i}.png"))
+        assert tok is not None and np.array_equal(arr, imgs[i])
+    # writes: same bytes as the in-process encoder, warnings and the skip rule travel back
+    from face_crop_plus_amd.utils import write_image
+    assert pool.write(str(tmp_path / "w.png"), imgs[0]) is True
+    write_image(str(tmp_path / "ref.png"), imgs[0])
+    assert (tmp_path / "w.png").read_bytes() == (tmp_path / "ref.png").read_bytes()
+    assert pool.write(str(tmp_path / "m.jpg"), imgs[1][..., 0].copy()) is True   # single-channel mask
+    with pytest.warns(UserWarning, match="Could not write"):
+        assert pool.write(str(tmp_path / "w.xyz"), imgs[0]) is False
+    with pytest.raises(RuntimeError, match="I/O worker"):
+        pool.write(str(tmp_path / "no_dir" / "w.ppm"), imgs[0])                   # a real I/O error is raised in the parent
+    assert pool.write(str(tmp_path / "after.png"), imgs[2]) is True               # ... and the worker lives on
+
+
+def test_unreadable_file_warns_and_threads_get_their_own_worker(pool, tmp_path):
+    from PIL import Image
+    (tmp_path / "bad.png").write_bytes(b"nope")
+    with pytest.warns(UserWarning, match="Could not read"):
+        assert pool.read(str(tmp_path / "bad.png")) == (None, None)
+    for i in range(6):
+        Image.fromarray(_img(40, 50, i)).save(tmp_path / f"t{i}.png")
+    pool.begin()
+    seen = set()
+
+    def job(i):
+        arr, tok = pool.read(str(tmp_path / f"t{i}.png"))
+        seen.add((threading.get_ident(), id(tok[0])))
+        ok = np.array_equal(arr, _img(40, 50, i))
+        pool.release([tok])
+        return ok
+    with ThreadPoolExecutor(2) as ex:
+        assert all(ex.map(job, range(6)))
+    assert len({w for _, w in seen}) <= 2 and len({t: w for t, w in seen}) == len({t for t, _ in seen})   # a thread keeps its worker
+    pool.begin()
+    with ThreadPoolExecutor(3) as ex:                                           # more threads than readers: the third fails loudly
+        barrier = threading.Barrier(3)
+        def claim(i):
+            barrier.wait()
+            return pool.read(str(tmp_path / f"t{i}.png"))
+        futs = [ex.submit(claim, i) for i in range(3)]
+        errs = [f.exception() for f in futs]
+    assert sum(e is not None for e in errs) == 1 and "more I/O threads" in str([e for e in errs if e][0])
+
+
+def test_workers_exit_with_the_pool(tmp_path):
+    from face_crop_plus_amd._io_pool import IOProcesses
+    p = IOProcesses(1, 1, ring_mb=1)
+    pids = [w.proc.pid for w in p._readers + p._writers]
+    p.close()
+    for pid in pids:
+        with pytest.raises(OSError):
+            os.kill(pid, 0)                                                     # gone (and reaped)

@@ -20,9 +20,13 @@ with tempfile.TemporaryDirectory() as d:
     c = Cropper(resize_size=size, batch_size=64, num_processes=nproc, device="cuda:0", weights={"retinaface": "generated"})
     if io:
         c.io_threads = io
+    if os.environ.get("FCP_IO_PROCS"):                      # "readers,writers"
+        c.io_processes = tuple(int(v) for v in os.environ["FCP_IO_PROCS"].split(","))
     c.process_dir(src, dst + "_warm", desc=None)
     t0 = time.time()
     c.process_dir(src, dst, desc=None)
     dt = time.time() - t0
-    print(f"{n} jpg {size}x{size}, num_processes={nproc}, io_threads={c.io_threads}, host cores {os.cpu_count()}: "
+    procs = c._io_procs
+    print(f"{n} jpg {size}x{size}, num_processes={nproc}, io_threads={c.io_threads}, io_processes="
+          f"{(procs.readers, procs.writers) if procs is not None else 'off (threads)'}, host cores {os.cpu_count()}: "
           f"{n / dt:.1f} images/s ({len(os.listdir(dst))} crops written)")
