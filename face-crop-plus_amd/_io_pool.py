@@ -3,25 +3,30 @@ read side, ``cropper.py:554-609`` write side).
 
 Round 3 ran Pillow on an I/O thread pool: 1300-1440 images/s end to end against 2600 for the device path alone — the
 rest was Python under the GIL (array conversion, EXIF handling, encoder set-up, executor bookkeeping).  Here every I/O
-thread of the executor owns ONE forked worker process and does a blocking request / reply with it, so the thread
-architecture of ``process_dir`` (prefetch depth, back-pressure, error surfacing, file naming, warn-and-skip) is
-unchanged while the CPU-heavy part runs outside the parent's interpreter:
+thread of the executor owns ONE worker process and does a blocking request / reply with it, so the thread architecture
+of ``process_dir`` (prefetch depth, back-pressure, error surfacing, file naming, warn-and-skip) is unchanged while the
+CPU-heavy part runs outside the parent's interpreter:
 
-* read:  the worker decodes the file (``utils.read_image``: same EXIF / RGB rules) into its own ring of shared
-  memory (an anonymous ``MAP_SHARED`` mapping created before the fork: no /dev/shm, no pickling of pixels) and replies
-  ``(offset, h, w)``; the parent wraps the region as a numpy view and gives it back (``release``) once the batch that
-  used it is done.  A worker NEVER waits for ring space — an image that does not fit right now travels through the pipe
-  instead — so a ring that is too small for a batch of 4K frames costs speed, not progress.
-* write: the parent sends the crop's bytes through the pipe (``send_bytes``: a syscall, GIL released), the worker
-  encodes with ``utils.write_image`` (same encoder table, same warn-and-skip) and replies.
+* read:  the worker decodes the file (``_io_codec.read_image``: same EXIF / RGB rules) into its own ring of shared
+  memory (a ``memfd`` mapped by both sides: no /dev/shm quota, no pickling of pixels) and replies ``(offset, shape)``;
+  the parent wraps the region as a numpy view and gives it back (``release``) once the batch that used it is done.
+  A worker NEVER waits for ring space — an image that does not fit right now travels through the socket instead — so a
+  ring that is too small for a batch of 4K frames costs speed, not progress.
+* write: the parent sends the crop's bytes through the socket (a syscall, GIL released), the worker encodes with
+  ``_io_codec.write_image`` (same encoder table, same warn-and-skip) and replies.
 
-Workers are forked (like ``torch.utils.data.DataLoader``'s): they never touch the GPU runtime, only numpy + Pillow, and
-leave through ``os._exit``.  ``FCP_IO_PROCESSES=0`` keeps everything on threads (the round-3 behaviour).
+Workers are fresh interpreters (``python -m face_crop_plus_amd._io_pool`` with the ring / control / socket descriptors
+passed explicitly): they import numpy + Pillow only.  They are deliberately NOT forked from the parent: a fork of a
+process that holds HIP streams, events and pinned buffers in other threads' thread-local storage destroys those objects
+in the child (CPython clears the dead threads' state after fork), i.e. calls into a HIP runtime that does not exist
+there (measured: "terminate called without an active exception" with two GPU worker threads).
+``FCP_IO_PROCESSES=0`` keeps everything on threads (the round-3 behaviour).
 """
 from __future__ import annotations
 
 import mmap
 import os
+import sys
 import threading
 import warnings
 from collections import OrderedDict
@@ -31,69 +36,86 @@ import numpy as np
 RING_MB = int(os.environ.get("FCP_IO_RING_MB", "128"))
 
 
-def _worker(conn, ring: mmap.mmap | None, ring_bytes: int, ctl: mmap.mmap, slot: int, inherited):
-    """Child process: serve requests until the pipe closes.  Never returns (``os._exit``)."""
+def _serve(conn, ring, ring_bytes: int, ctl, slot: int):
+    """Worker process: serve requests until the socket closes."""
+    from ._io_codec import read_image, write_image
+    consumed = np.frombuffer(ctl, dtype=np.int64)          # consumed[slot]: bytes the parent has given back (monotonic)
+    produced = 0                                            # bytes handed out so far, incl. skipped ring tails (monotonic)
+    while True:
+        try:
+            msg = conn.recv()
+        except (EOFError, OSError):
+            return
+        if msg is None:
+            return
+        kind = msg[0]
+        try:
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                if kind == "read":
+                    img = read_image(msg[1])
+                    notes = [str(w.message) for w in caught]
+                    if img is None:
+                        conn.send(("none", notes))
+                        continue
+                    need = img.nbytes
+                    pos = produced % ring_bytes if ring_bytes else 0
+                    skip = ring_bytes - pos if ring_bytes and pos + need > ring_bytes else 0
+                    if ring_bytes and need <= ring_bytes and produced + skip + need - int(consumed[slot]) <= ring_bytes:
+                        off = (pos + skip) % ring_bytes
+                        np.frombuffer(ring, dtype=np.uint8, count=need, offset=off)[:] = img.reshape(-1)
+                        produced += skip + need
+                        conn.send(("ring", off, img.shape, skip + need, notes))
+                    else:                                   # no room right now: through the socket, never wait
+                        conn.send(("pipe", img.shape, notes))
+                        conn.send_bytes(memoryview(np.ascontiguousarray(img)).cast("B"))
+                elif kind == "write":
+                    _, path, shape = msg
+                    pixels = np.frombuffer(conn.recv_bytes(), dtype=np.uint8).reshape(shape)
+                    ok = write_image(path, pixels)
+                    conn.send(("done", bool(ok), [str(w.message) for w in caught]))
+                else:
+                    conn.send(("error", f"unknown request {kind!r}"))
+        except Exception as e:                              # noqa: BLE001 - reported to the parent, which re-raises
+            conn.send(("error", f"{type(e).__name__}: {e}"))
+
+
+def _main(argv):
+    """``python -m face_crop_plus_amd._io_pool <sock_fd> <ring_fd | -1> <ring_bytes> <ctl_fd> <ctl_bytes> <slot>``"""
+    from multiprocessing.connection import Connection
+    sock_fd, ring_fd, ring_bytes, ctl_fd, ctl_bytes, slot = (int(a) for a in argv)
+    ring = mmap.mmap(ring_fd, ring_bytes) if ring_fd >= 0 else None
+    ctl = mmap.mmap(ctl_fd, ctl_bytes)
     try:
-        for c in inherited:                                 # parent-side pipe ends of the workers forked before this one:
-            try:                                            # held open here they would keep those workers from ever
-                c.close()                                   # seeing EOF when the parent goes away
-            except OSError:
-                pass
-        from .utils import read_image, write_image
-        consumed = np.frombuffer(ctl, dtype=np.int64)      # consumed[slot]: bytes the parent has given back (monotonic)
-        produced = 0                                        # bytes handed out so far, incl. skipped ring tails (monotonic)
-        while True:
-            try:
-                msg = conn.recv()
-            except (EOFError, OSError):
-                break
-            if msg is None:
-                break
-            kind = msg[0]
-            try:
-                with warnings.catch_warnings(record=True) as caught:
-                    warnings.simplefilter("always")
-                    if kind == "read":
-                        img = read_image(msg[1])
-                        notes = [str(w.message) for w in caught]
-                        if img is None:
-                            conn.send(("none", notes))
-                            continue
-                        need = img.nbytes
-                        pos = produced % ring_bytes if ring_bytes else 0
-                        skip = ring_bytes - pos if ring_bytes and pos + need > ring_bytes else 0
-                        if ring_bytes and need <= ring_bytes and produced + skip + need - int(consumed[slot]) <= ring_bytes:
-                            off = (pos + skip) % ring_bytes
-                            np.frombuffer(ring, dtype=np.uint8, count=need, offset=off)[:] = img.reshape(-1)
-                            produced += skip + need
-                            conn.send(("ring", off, img.shape, skip + need, notes))
-                        else:                               # no room right now: through the pipe, never wait
-                            conn.send(("pipe", img.shape, notes))
-                            conn.send_bytes(memoryview(np.ascontiguousarray(img)).cast("B"))
-                    elif kind == "write":
-                        _, path, shape = msg
-                        pixels = np.frombuffer(conn.recv_bytes(), dtype=np.uint8).reshape(shape)
-                        ok = write_image(path, pixels)
-                        conn.send(("done", bool(ok), [str(w.message) for w in caught]))
-                    else:
-                        conn.send(("error", f"unknown request {kind!r}"))
-            except Exception as e:                          # noqa: BLE001 - reported to the parent, which re-raises
-                conn.send(("error", f"{type(e).__name__}: {e}"))
+        _serve(Connection(sock_fd), ring, ring_bytes, ctl, slot)
     finally:
-        os._exit(0)                                         # no atexit handlers / destructors of the forked parent state
+        os._exit(0)
 
 
 class _Worker:
     """Parent-side handle of one worker process; used by exactly one I/O thread at a time."""
 
-    def __init__(self, ctx, ctl, slot, ring_bytes, earlier=()):
+    def __init__(self, ctl_fd, ctl_bytes, ctl, slot, ring_bytes):
+        import socket
+        import subprocess
+        from multiprocessing.connection import Connection
         self.ring_bytes = ring_bytes
-        self.ring = mmap.mmap(-1, ring_bytes) if ring_bytes else None       # anonymous + shared: inherited by the fork
-        self.conn, child = ctx.Pipe(duplex=True)
-        self.proc = ctx.Process(target=_worker, args=(child, self.ring, ring_bytes, ctl, slot,
-                                                      [w.conn for w in earlier] + [self.conn]), daemon=True)
-        self.proc.start()
-        child.close()
+        self.ring, ring_fd = None, -1
+        if ring_bytes:
+            ring_fd = os.memfd_create(f"fcp-io-ring-{slot}")
+            os.ftruncate(ring_fd, ring_bytes)
+            self.ring = mmap.mmap(ring_fd, ring_bytes)
+        mine, theirs = socket.socketpair()
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # the directory holding the import shim
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        fds = [theirs.fileno(), ctl_fd] + ([ring_fd] if ring_fd >= 0 else [])
+        self.proc = subprocess.Popen([sys.executable, "-m", "face_crop_plus_amd._io_pool", str(theirs.fileno()), str(ring_fd),
+                                      str(ring_bytes), str(ctl_fd), str(ctl_bytes), str(slot)], pass_fds=fds, env=env,
+                                     stdin=subprocess.DEVNULL)
+        theirs.close()
+        if ring_fd >= 0:
+            os.close(ring_fd)                       # the mappings keep the memory alive
+        self.conn = Connection(mine.detach())
         self.slot, self.ctl = slot, np.frombuffer(ctl, dtype=np.int64)
         self.lock = threading.Lock()
         self.regions = OrderedDict()                 # seq -> [bytes, released]; the released PREFIX is given back
@@ -152,10 +174,11 @@ class _Worker:
             self.conn.send(None)
         except (OSError, ValueError):
             pass
-        self.proc.join(timeout=2)
-        if self.proc.is_alive():
-            self.proc.terminate()
-            self.proc.join(timeout=2)
+        try:
+            self.proc.wait(timeout=2)
+        except Exception:                            # noqa: BLE001 - subprocess.TimeoutExpired
+            self.proc.kill()
+            self.proc.wait(timeout=2)
         self.conn.close()
         if self.ring is not None:
             try:
@@ -166,20 +189,24 @@ class _Worker:
 
 class IOProcesses:
     """``readers`` decode workers (each with a ring) + ``writers`` encode workers; I/O threads borrow one each through
-    ``reader()`` / ``writer()`` (thread-local, so a worker's pipe is only ever used by one thread)."""
+    ``read()`` / ``write()`` (thread-local, so a worker's socket is only ever used by one thread)."""
 
     def __init__(self, readers: int, writers: int, ring_mb: int = RING_MB):
-        import multiprocessing as mp
-        ctx = mp.get_context("fork")
-        self._ctl = mmap.mmap(-1, 8 * (readers + writers))
+        if not hasattr(os, "memfd_create"):
+            raise OSError("os.memfd_create is unavailable on this platform")
+        n = readers + writers
+        self._ctl_bytes = max(mmap.PAGESIZE, 8 * n)
+        ctl_fd = os.memfd_create("fcp-io-ctl")
+        os.ftruncate(ctl_fd, self._ctl_bytes)
+        self._ctl = mmap.mmap(ctl_fd, self._ctl_bytes)
         self._readers, self._writers = [], []
-        with warnings.catch_warnings():
-            # "os.fork() was called ... multi-threaded": true and intended, the children run numpy + Pillow only
-            warnings.simplefilter("ignore", DeprecationWarning)
-            for i in range(readers):
-                self._readers.append(_Worker(ctx, self._ctl, i, ring_mb << 20, self._readers))
+        try:
+            for i in range(readers):                 # Popen returns at once: the interpreters start in parallel
+                self._readers.append(_Worker(ctl_fd, self._ctl_bytes, self._ctl, i, ring_mb << 20))
             for i in range(writers):
-                self._writers.append(_Worker(ctx, self._ctl, readers + i, 0, self._readers + self._writers))
+                self._writers.append(_Worker(ctl_fd, self._ctl_bytes, self._ctl, readers + i, 0))
+        finally:
+            os.close(ctl_fd)
         self._lock = threading.Lock()
         self.closed = False
         self.begin()
@@ -230,3 +257,7 @@ class IOProcesses:
             self.close()
         except Exception:                            # noqa: BLE001 - interpreter shutdown
             pass
+
+
+if __name__ == "__main__":
+    _main(sys.argv[1:])

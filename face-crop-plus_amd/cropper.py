@@ -75,7 +75,7 @@ class Cropper:
         self.num_std_landmarks = 5
         # host I/O threads of process_dir (decode prefetch + asynchronous encode/write around the GPU workers)
         self.io_threads = max(2, min(16, (os.cpu_count() or 4) // 2))
-        # ... and, by default, one forked decode / encode worker PROCESS behind every I/O thread (_io_pool.py): the
+        # ... and, by default, one decode / encode worker PROCESS behind every I/O thread (_io_pool.py): the
         # Pillow work leaves the parent's interpreter lock.  (readers, writers); None = sized from the host's cores;
         # FCP_IO_PROCESSES=0 (or io_processes = (0, 0)) keeps decode / encode on the threads
         self.io_processes = (0, 0) if os.environ.get("FCP_IO_PROCESSES", "1") == "0" else None
@@ -424,8 +424,8 @@ class Cropper:
             self._io_procs_active = None
 
     def _io_processes(self):
-        """The decode / encode worker processes of this Cropper (forked on first use, reused by later runs), or None
-        when they are switched off or cannot be had (no fork on this platform)."""
+        """The decode / encode worker processes of this Cropper (started on first use, reused by later runs), or None
+        when they are switched off or cannot be had on this platform."""
         want = self.io_processes
         if want is None:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
@@ -440,7 +440,7 @@ class Cropper:
         try:
             from ._io_pool import IOProcesses
             self._io_procs = IOProcesses(*want)
-        except (ValueError, OSError) as e:           # no "fork" start method / no processes left: threads still work
+        except (ValueError, OSError) as e:           # no memfd / no processes left on this host: threads still work
             import warnings
             warnings.warn(f"decode / encode worker processes unavailable ({e}): using I/O threads")
             self.io_processes, self._io_procs = (0, 0), None

@@ -84,6 +84,7 @@ def test_workers_exit_with_the_pool(tmp_path):
     from face_crop_plus_amd._io_pool import IOProcesses
     p = IOProcesses(1, 1, ring_mb=1)
     pids = [w.proc.pid for w in p._readers + p._writers]
+    assert p.write(str(tmp_path / 'x.png'), _img(8, 8, 0)) is True
     p.close()
     for pid in pids:
         with pytest.raises(OSError):

@@ -1,5 +1,5 @@
 """Run ONE conv-engine launch in a loop for ~N seconds (power / clock sampling with tools/smi_sample.sh).
-    python tools/loop_kernel.py chain|pair2|pair3|big3x3|halo|stem [seconds]"""
+    python tools/loop_kernel.py chain|pair2|pair3|big3x3|big1x1|dma1x1|dma3x3s2|halo|wide|stem|copy [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,6 +29,27 @@ elif what == "big3x3":
 elif what == "halo":
     pc = mk(32, 160, 3); x = sp(1, 1024, 192); 
     f = lambda: E.conv(pc, x.slice(0, 160), x.slice(160, 32), act_slope=0.2, tile_m=1, tile_n=32)
+elif what == "dma1x1":       # 128-row LDS-DMA kernel: 1x1 512 -> 128 @80x80 (layer 2's conv1)
+    pc = mk(128, 512, 1); x = sp(b, 80, 512); out = E.Act.empty(b, 80, 80, 128, dev, 1)
+    f = lambda: E.conv(pc, x, out, act_slope=0.0, tile_m=128, tile_n=128)
+elif what == "dma3x3s2":     # 128-row LDS-DMA kernel: 3x3 / 2 128 -> 128 (layer2.0.conv2)
+    pc = E.pack_conv(torch.randn(128, 128, 3, 3, generator=g) * (2 / 1152) ** 0.5, torch.randn(128, generator=g) * 0.1, None, 2, 1, dev, precision="f16x3")
+    x = sp(b, 160, 128); out = E.Act.empty(b, 80, 80, 128, dev, 1)
+    f = lambda: E.conv(pc, x, out, act_slope=0.0, tile_m=128, tile_n=128)
+elif what == "big1x1":       # 256-row kernel, short K: 1x1 1024 -> 256 @40x40
+    pc = mk(256, 1024, 1); x = sp(b, 40, 1024); out = E.Act.empty(b, 40, 40, 256, dev, 1)
+    f = lambda: E.conv(pc, x, out, act_slope=0.0, tile_m=256, tile_n=256)
+elif what == "wide":         # wide halo-tile kernel: 3x3 128 -> 128 @80x80 (layer 2's conv2)
+    pc = mk(128, 128, 3); x = sp(b, 80, 128); out = E.Act.empty(b, 80, 80, 128, dev, 1)
+    f = lambda: E.conv(pc, x, out, act_slope=0.0, tile_m=1, tile_n=128)
+elif what == "stem":         # uint8 -> stem conv + pool + layer1.0.conv1
+    from face_crop_plus_amd import weights
+    sd = weights.generate_state_dict("retinaface")
+    ps = E.pack_stem_fused(sd["body.conv1.weight"], E.bn_of(sd, "body.bn1"), dev, cin_perm=[2, 1, 0])
+    c1 = E.pack_conv(sd["body.layer1.0.conv1.weight"], None, E.bn_of(sd, "body.layer1.0.bn1"), 1, 0, dev)
+    imgs = torch.randint(0, 256, (b, 640, 640, 3), generator=g, dtype=torch.uint8).to(dev)
+    o = E.Act.empty(b, 160, 160, 64, dev, 1); t1 = E.Act.empty(b, 160, 160, 64, dev, 1)
+    f = lambda: E.stem_relu_pool_u8(ps, imgs, o, conv1=c1, t1=t1)
 elif what == "copy":
     a = torch.empty(1 << 28, device=dev); c = torch.empty_like(a)
     f = lambda: c.copy_(a)
