@@ -558,6 +558,15 @@ def main():
         }
         if extra is not None:
             line["extra"] = extra
+            # the north-star geometry (batch 32 @1024^2, detect + align + crop: the per-GPU rate that decides >= 10 k
+            # faces/s on 8 GPUs) also inside `config`, which every consumer of the line keeps
+            ns = extra.get("c3_detect_align_crop_1024", {})
+            if "value" in ns:
+                line["config"]["north_star_geometry"] = {
+                    "workload": ns["workload"], "value": ns["value"], "unit": ns["unit"], "ms_per_step": ns["ms_per_step"],
+                    "steps": ns["steps"], "warmup": ns["warmup"], "roofline_frac": ns["roofline"]["frac"],
+                    "roofline_frac_timed": ns["roofline"].get("frac_timed")}
+                line["roofline"]["north_star_geometry_frac"] = ns["roofline"]["frac"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

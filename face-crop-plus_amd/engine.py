@@ -194,6 +194,25 @@ def _pick_tile_n(cout: int, m: int) -> int:
     return 64
 
 
+_props_lock = threading.Lock()
+_props: dict = {}
+
+
+def device_props(dev=None):
+    """``torch.cuda.get_device_properties`` behind a lock and a cache.  process_dir's GPU worker threads reach their first
+    launch at the same time, and concurrent first calls into torch's lazy device bookkeeping raced on the MI355X boxes
+    ("AssertionError: Invalid device id" from a worker thread, then an abort at teardown)."""
+    idx = torch.cuda.current_device() if dev is None else (torch.device(dev).index if torch.device(dev).index is not None
+                                                           else torch.cuda.current_device())
+    got = _props.get(idx)
+    if got is None:
+        with _props_lock:
+            got = _props.get(idx)
+            if got is None:
+                got = _props[idx] = torch.cuda.get_device_properties(idx)
+    return got
+
+
 BIG_TILES = os.environ.get("FCP_BIG_TILES", "1") != "0"   # offer the 256-row kernel to the autotuner
 BALANCE_TAIL = os.environ.get("FCP_BALANCE_TAIL", "1") != "0"   # and its balanced M-tile schedule (FCP_CONV_BALANCE_TAIL)
 
@@ -239,7 +258,7 @@ class Autotune:
     @classmethod
     def section(cls):
         if cls._disk_section is None:
-            prop = torch.cuda.get_device_properties(torch.cuda.current_device())
+            prop = device_props()
             # the marketing name differs between boxes of one pool ("AMD Radeon Graphics" / "AMD Instinct MI355X"):
             # the ISA name + CU count identify the part
             arch = getattr(prop, "gcnArchName", prop.name).split(":")[0]

@@ -66,6 +66,7 @@ class RetinaFace:
         with torch.cuda.device(device), E.default_precision(precision):
             self._p = self._pack(sd, device)
         self.precision = E.resolve_precision(precision)
+        E.device_props(device)          # cached here, on the loading thread: the worker threads only ever read the cache
         # Range / accuracy guard of the fp16x3 path (``selfcheck``): FCP_SELFCHECK=1 always, 0 never; by default ("auto")
         # whenever the weights come from a checkpoint — a file, the hub cache or a download — i.e. are not this package's
         # own generated ones or a state dict the caller built in memory.
@@ -277,7 +278,7 @@ class RetinaFace:
         bounds = [n * i // k for i in range(k + 1)]
         side = self._side_streams(dev, k)
         # each sub-batch lays out the last dispatch round of its 256-row conv launches for its share of the CUs
-        cus = torch.cuda.get_device_properties(dev).multi_processor_count // k if self.split_cu_budget else 0
+        cus = E.device_props(dev).multi_processor_count // k if self.split_cu_budget else 0
         for st, a, b in zip(side, bounds[:-1], bounds[1:]):
             tuned = len(E.Autotune.cache)
             st.wait_stream(cur)
