@@ -95,7 +95,7 @@ def _main(argv):
 class _Worker:
     """Parent-side handle of one worker process; used by exactly one I/O thread at a time."""
 
-    def __init__(self, ctl_fd, ctl_bytes, ctl, slot, ring_bytes):
+    def __init__(self, ctl_fd, ctl_bytes, ctl, slot, ring_bytes, register=None):
         import socket
         import subprocess
         from multiprocessing.connection import Connection
@@ -117,6 +117,10 @@ class _Worker:
             os.close(ring_fd)                       # the mappings keep the memory alive
         self.conn = Connection(mine.detach())
         self.slot, self.ctl = slot, np.frombuffer(ctl, dtype=np.int64)
+        self.pinned = False
+        if self.ring is not None and register is not None:
+            self.pinned = register(self.ring, ring_bytes)     # page-locked for HIP: uploads DMA straight out of the ring
+            self._unregister = register
         self.lock = threading.Lock()
         self.regions = OrderedDict()                 # seq -> [bytes, released]; the released PREFIX is given back
         self.seq = 0
@@ -150,6 +154,10 @@ class _Worker:
             self.regions[self.seq] = [nbytes, False]
             return arr, (self, self.seq)
 
+    @staticmethod
+    def is_pinned(token) -> bool:
+        return token is not None and token[0].pinned
+
     def release(self, seq):
         with self.lock:
             self.regions[seq][1] = True
@@ -181,6 +189,9 @@ class _Worker:
             self.proc.wait(timeout=2)
         self.conn.close()
         if self.ring is not None:
+            if self.pinned:
+                self._unregister(self.ring, 0)
+                self.pinned = False
             try:
                 self.ring.close()
             except BufferError:                      # a numpy view of a region is still alive somewhere: leave it to the GC
@@ -191,7 +202,9 @@ class IOProcesses:
     """``readers`` decode workers (each with a ring) + ``writers`` encode workers; I/O threads borrow one each through
     ``read()`` / ``write()`` (thread-local, so a worker's socket is only ever used by one thread)."""
 
-    def __init__(self, readers: int, writers: int, ring_mb: int = RING_MB):
+    def __init__(self, readers: int, writers: int, ring_mb: int = RING_MB, register=None):
+        """``register(mmap, nbytes) -> bool``: optional hook that page-locks a ring for the GPU runtime (nbytes == 0:
+        undo it); this module itself stays free of torch / HIP imports."""
         if not hasattr(os, "memfd_create"):
             raise OSError("os.memfd_create is unavailable on this platform")
         n = readers + writers
@@ -202,7 +215,7 @@ class IOProcesses:
         self._readers, self._writers = [], []
         try:
             for i in range(readers):                 # Popen returns at once: the interpreters start in parallel
-                self._readers.append(_Worker(ctl_fd, self._ctl_bytes, self._ctl, i, ring_mb << 20))
+                self._readers.append(_Worker(ctl_fd, self._ctl_bytes, self._ctl, i, ring_mb << 20, register))
             for i in range(writers):
                 self._writers.append(_Worker(ctl_fd, self._ctl_bytes, self._ctl, readers + i, 0))
         finally:
@@ -239,6 +252,10 @@ class IOProcesses:
 
     def write(self, path, pixels):
         return self._mine("w", self._free_w).write(path, pixels)
+
+    @staticmethod
+    def pinned_flags(tokens):
+        return [_Worker.is_pinned(t) for t in tokens]
 
     @staticmethod
     def release(tokens):

@@ -51,9 +51,12 @@ def _staging(nbytes: int) -> torch.Tensor:
     return buf
 
 
-def build_batch(images, size=512, padding_mode: str = "constant", device="cuda:0"):
+def build_batch(images, size=512, padding_mode: str = "constant", device="cuda:0", pinned=None):
     """list of (h,w,3) uint8 RGB arrays -> (batch (N,H,W,3) uint8 *device* tensor,
-    unscales (N,) float64, paddings (N,4) int64 [t,b,l,r])."""
+    unscales (N,) float64, paddings (N,4) int64 [t,b,l,r]).  ``pinned``: optional per-image flags — True for an array
+    that already lives in page-locked memory registered with HIP (the decode workers' shared-memory rings,
+    ``_io_pool.py``): it is uploaded straight from where it is; the others are packed into the pinned staging blob
+    first.  The caller keeps such arrays alive and unchanged until it has synchronised with the stream."""
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("face_crop_plus_amd runs on an AMD GPU only; there is no CPU fallback")
@@ -77,16 +80,30 @@ def build_batch(images, size=512, padding_mode: str = "constant", device="cuda:0
         out = torch.empty((n, size[1], size[0], 3), dtype=torch.uint8, device=device)
         if n == 0:
             return out, np.zeros((0,)), np.zeros((0, 4), np.int64)
-        stage = _staging(off)
-        view = stage.numpy()
-        for it, image in zip(items, images):
-            o = int(it["src_off"])
-            view[o:o + image.size] = np.ascontiguousarray(image).reshape(-1)
         blob = torch.empty(off, dtype=torch.uint8, device=device)
-        blob.copy_(stage[:off], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        _tls.event = ev
+        direct = [bool(pinned[i]) and images[i].flags.c_contiguous for i in range(n)] if pinned is not None else [False] * n
+        staged = [i for i in range(n) if not direct[i]]
+        if staged:
+            # staged images are packed back to back into the pinned staging blob; when ALL are staged that is the device
+            # layout itself and one copy moves the lot
+            stage = _staging(sum(images[i].size for i in staged))
+            view, so = stage.numpy(), 0
+            for i in staged:
+                image = images[i]
+                view[so:so + image.size] = np.ascontiguousarray(image).reshape(-1)
+                if len(staged) < n:
+                    o = int(items[i]["src_off"])
+                    blob[o:o + image.size].copy_(stage[so:so + image.size], non_blocking=True)
+                so += image.size
+            if len(staged) == n:
+                blob.copy_(stage[:off], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            _tls.event = ev
+        for i in range(n):
+            if direct[i]:                                          # DMA straight out of the registered ring
+                o, image = int(items[i]["src_off"]), images[i]
+                blob[o:o + image.size].copy_(torch.from_numpy(image.reshape(-1)), non_blocking=True)
         items_dev = torch.from_numpy(items.view(np.uint8)).to(device)
         N.check(lib.fcp_build_batch_u8(N.ptr(blob), off, items.ctypes.data, N.ptr(items_dev), n, size[1], size[0],
                                        border_code(padding_mode), N.ptr(out), N.stream_ptr()), "fcp_build_batch_u8")

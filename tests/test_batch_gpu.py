@@ -93,3 +93,31 @@ def test_bad_items_are_rejected(device):
         build_batch([np.zeros((4, 4), np.uint8)], 16, "constant", device)
     empty, u, p = build_batch([], 16, "constant", device)
     assert empty.shape == (0, 16, 16, 3) and p.shape == (0, 4)
+
+
+def test_build_batch_direct_upload_from_registered_rings(tmp_path, device):
+    """process_dir's decode workers hand over images inside page-locked shared-memory rings; build_batch uploads those
+    straight from the ring.  All-pinned, mixed and all-staged batches must give the same bytes."""
+    from PIL import Image
+    from face_crop_plus_amd import Cropper
+    from face_crop_plus_amd._io_pool import IOProcesses
+    from face_crop_plus_amd.batch import build_batch
+    rng = np.random.default_rng(3)
+    imgs = [rng.integers(0, 256, (int(rng.integers(90, 300)), int(rng.integers(90, 300)), 3), dtype=np.uint8) for _ in range(7)]
+    for i, im in enumerate(imgs):
+        Image.fromarray(im).save(tmp_path / f"{i}.png")
+    pool = IOProcesses(1, 1, ring_mb=4, register=Cropper._pin_ring)
+    try:
+        got = [pool.read(str(tmp_path / f"{i}.png")) for i in range(7)]
+        assert all(np.array_equal(a, im) for (a, _), im in zip(got, imgs))
+        flags = pool.pinned_flags([t for _, t in got])
+        assert all(flags), "the ring was not registered as page-locked memory"
+        want = build_batch(imgs, (256, 192), "constant", device)[0]
+        ring_imgs = [a for a, _ in got]
+        assert torch.equal(build_batch(ring_imgs, (256, 192), "constant", device, flags)[0], want)
+        mixed = [a if i % 2 else a.copy() for i, a in enumerate(ring_imgs)]
+        assert torch.equal(build_batch(mixed, (256, 192), "constant", device, [bool(i % 2) for i in range(7)])[0], want)
+        torch.cuda.synchronize()
+        pool.release([t for _, t in got])
+    finally:
+        pool.close()
