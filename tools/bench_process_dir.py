@@ -22,6 +22,8 @@ with tempfile.TemporaryDirectory() as d:
         c.io_threads = io
     if os.environ.get("FCP_IO_PROCS"):                      # "readers,writers"
         c.io_processes = tuple(int(v) for v in os.environ["FCP_IO_PROCS"].split(","))
+    if os.environ.get("FCP_SWITCH_US"):
+        sys.setswitchinterval(float(os.environ["FCP_SWITCH_US"]) * 1e-6)
     c.process_dir(src, dst + "_warm", desc=None)
     t0 = time.time()
     c.process_dir(src, dst, desc=None)
