@@ -3,7 +3,7 @@
 // Injected with `FCP_BUILD_FLAGS="-include tools/probes/fcp_no_mfma.h"`; results are garbage by construction.
 #pragma once
 template <class A, class B, class C>
-__device__ __forceinline__ C fcp_nop_mfma16(A a, B b, C c) {
+__attribute__((device)) __attribute__((always_inline)) inline C fcp_nop_mfma16(A a, B b, C c) {
   asm volatile("" : "+v"(c) : "v"(a), "v"(b));
   return c;
 }
