@@ -21,8 +21,6 @@ LIB = os.path.join(CSRC, "libfcp_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
-if os.environ.get("FCP_BUILD_PROFILING") == "1":      # FCP_CONV_ABLATE knobs (tools/bench_c3.py etc.); use --force
-    FLAGS.append("-DFCP_CONV_PROFILING")
 FLAGS += [f"-D{d}" for d in os.environ.get("FCP_BUILD_DEFINES", "").split()]   # experiment builds on the GPU box only
 FLAGS += os.environ.get("FCP_BUILD_FLAGS", "").split()                          # e.g. -include tools/probes/fcp_no_mfma.h
 

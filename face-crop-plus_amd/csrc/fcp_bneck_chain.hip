@@ -43,9 +43,7 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef FCP_CHAIN_STORE_AUX
-#define FCP_CHAIN_STORE_AUX 2     // cache policy of the `out` stores of the chunk loop (0 default, 2 nt, 16 sc1)
-#endif
+constexpr int FCP_CHAIN_STORE_AUX = 2;   // cache policy of the `out` stores of the chunk loop: nt (0 default / 16 sc1 measured equal)
 
 struct ChainK {
   const float* t1;  unsigned t1_bytes;  int t1_ld;
@@ -57,7 +55,6 @@ struct ChainK {
   float* t1n;       int t1n_ld;
   int n, h, w, M;
   int nt_store;
-  int ablate;   // profiling builds only (FCP_CHAIN_ABLATE): 1 no out stores, 2 no residual loads, 4 no phase-1 loop, 8 no chunk loop, 16 half the filter DMAs
 };
 
 // Pixels per workgroup tile: BMT = 128 (4 waves, up to two workgroups per CU; the default) or 256 (8 waves, one workgroup per
@@ -79,11 +76,7 @@ constexpr int r0_bytes(int bmt, int cw, int cn, bool has_c2) { return has_c2 ? 2
 // registers, so the tile is only needed until they have been read.  That is what lets the 256-wide pair fit at all
 // (144 + 128 KiB otherwise) and brings the 128-wide pairs down to 80 KiB: TWO workgroups per CU, the second one's
 // MFMAs under the first one's epilogue (FCP_CHAIN_NOALIAS: the 128-wide pairs as before, 128-144 KiB, one per CU).
-#ifdef FCP_CHAIN_NOALIAS
-constexpr bool alias_t2(int bmt, int cw, int cn, bool has_c2) { return !has_c2 && r0_bytes(bmt, cw, cn, has_c2) + bmt * cw * 4 > 160 * 1024; }
-#else
 constexpr bool alias_t2(int bmt, int cw, int cn, bool has_c2) { return !has_c2; }
-#endif
 constexpr int lds_bytes(int bmt, int cw, int cn, bool has_c2) {   // 80 KiB (two per CU) | 112-160 KiB
   const int r0 = r0_bytes(bmt, cw, cn, has_c2), t2 = bmt * cw * 4;
   return !alias_t2(bmt, cw, cn, has_c2) ? r0 + t2 : (r0 > w1b_off(bmt) + t2 ? r0 : w1b_off(bmt) + t2);
@@ -125,24 +118,14 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   // pair 451 vs 493 us); with TWO workgroups per CU the other workgroup's wave covers a burst, while spread instructions
   // stretch phase 2 to 5250 cycles for 768 cycles of MFMAs: the burst wins there (layer-2 pair 644 -> 525-548 us).  The
   // conv2 forms (two per CU, few filter pieces) are 1.5 % better spread.  profiles/r03_probes.md.
-#if defined(FCP_CHAIN_BURST)
-  constexpr bool SPREAD = false;
-#elif defined(FCP_CHAIN_SPREAD)
-  constexpr bool SPREAD = W1DB;
-#else
   constexpr bool SPREAD = W1DB && (HAS_C2 || WPS == 1);
-#endif
   // Rotated chunk loop (experiment builds, FCP_CHAIN_ROT; the one-wave-per-SIMD pair forms: 512 registers per wave): phase 3
   // of chunk j - 1 is issued BETWEEN the phase-2 MFMAs of chunk j (phase 2 is one dependent chain on a single accumulator,
   // phase 3 is 6 TN3 MFMAs on TN3 independent accumulators); conv1' slice j is then fetched during chunk j and the T3
   // fragments of chunk j are read into registers at the end of chunk j.  Bit-identical (tools/fuzz_chain.py), 10 % fewer
   // cycles per chunk in the probes (8320 -> 7490) and 7 % MORE wall time on the layer-3 pair (440 -> 471 us; the
   // 128 -> 512 -> 256 pair 827-867 -> 820-837): not the default.  profiles/r03_probes.md.
-#ifdef FCP_CHAIN_ROT
-  constexpr bool ROT = !HAS_C2 && W1DB && SPREAD && WPS == 1 && TN3 % CS == 0;
-#else
   constexpr bool ROT = false;
-#endif
   constexpr int PQ = ROT ? TN3 / CS : 0;                // phase-3 MFMAs behind every phase-2 MFMA (6 TN3 against 6 CS)
   static_assert(!ROT || (TN3 % CS == 0 && PQ >= 1), "rotated loop: TN3 must be a multiple of CS");
   constexpr bool W1PRE = !ROT && W1DB && (HAS_C2 ? CN <= 64 || WPS == 1 : CN <= 128 && WPS == 1);   // conv1' fragments of a chunk requested under phase 2 (registers permitting)
@@ -231,7 +214,6 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
       }
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
-        if (FCP_ABLATE(p, 16) && (i & 1)) continue;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + LR * i * ROWB), 16,
                                                  (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
       }
@@ -248,11 +230,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     // stages, slices fetched TWO ahead — the third stage costs no LDS, it lies in the T2 region, which is only written by the
     // conv2 epilogue — measured equal, 1327-1341 vs 1328-1340 us: with two workgroups per CU the other one covers the DMA
     // round trip already; profiles/r03_probes.md.)
-#ifdef FCP_CHAIN_C2_STAGES3
-    constexpr int NST = 3;
-#else
     constexpr int NST = 2;
-#endif
     static_assert(NST * STAGE <= T2_OFF + BMT * C * 4, "phase-1 stages must fit region 0 + T2");
     set_tap(0, 0, 0);
     dma_slice(0, 0);
@@ -261,7 +239,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
       dma_slice(1, 1);
     }
     int stage = 0;
-    const int kt_end = FCP_ABLATE(p, 4) ? 0 : KT;
+    const int kt_end = KT;
     for (int kt = 0; kt < kt_end; ++kt) {
       // slice kt has landed (the one or two younger slices may still fly) and every wave is done with slice kt - 1
       if (NST == 3 && kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
@@ -367,7 +345,6 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   auto dma_w3 = [&](int j, int buf) {
 #pragma unroll
     for (int i = 0; i < PW3; ++i) {
-      if (FCP_ABLATE(p, 16) && (i & 1)) continue;
       const int g = wave_u * PW3 + i, sl = g >> 2, r = (g & 3) * 8 + (lane >> 3);
       char* dst = lds + W3B_OFF + buf * W3CH + sl * 4096 + (g & 3) * 8 * ROWB;
       const unsigned src = (unsigned)((j * 32 + r) * (CW * 4) + sl * 128 + (((lane & 7) ^ swz(r)) << 4));
@@ -379,7 +356,6 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     char* dst = lds + W1B_OFF + buf * (CN * ROWB) + wave_u * (CN / NW) * ROWB;
 #pragma unroll
     for (int i = 0; i < PW1; ++i) {
-      if (FCP_ABLATE(p, 16) && (i & 1)) continue;
       const int r = wave_u * (CN / NW) + 8 * i + (lane >> 3);
       const unsigned src = (unsigned)(r * (NOUT * 4) + j * 128 + (((lane & 7) ^ swz(r)) << 4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + 8 * i * ROWB), 16, (int)src, 0, 0, 0);
@@ -389,7 +365,6 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   constexpr int NDMA = PW3 + PW1;
   auto dma_one = [&](auto kc, int j, int buf) {
     constexpr int k = decltype(kc)::value;
-    if (FCP_ABLATE(p, 16) && (k & 1)) return;       // profiling builds: half of the filter DMA instructions (wrong results)
     if constexpr (k < PW3) {
       const int g = wave_u * PW3 + k, sl = g >> 2, r = (g & 3) * 8 + (lane >> 3);
       char* dst = lds + W3B_OFF + buf * W3CH + sl * 4096 + (g & 3) * 8 * ROWB;
@@ -417,15 +392,8 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   // 32-channel chunk.  A wave stages, finishes and re-reads (phase 3) only its own rows of the epilogue tile, so the three
   // steps of a chunk need no workgroup barrier between them and the four waves may drift apart inside a chunk (one wave's
   // MFMAs beside another's epilogue); what the waves share are the filter buffers: ONE barrier per chunk.
-#ifdef FCP_CHAIN_REG_EPI
-  // (register epilogue: after the lane permutations lane l holds channel group l >> 4 of rows (l & 15) and 16 + (l & 15);
-  //  a store instruction still covers 16 rows x 64 bytes)
-  const int eq = lane >> 4;
-  const int erow0 = wave * 32 + (lane & 15);
-#else
   const int eq = lane & 3;
   const int erow0 = wave * 32 + (lane >> 2);
-#endif
   const long em0 = (long)tile_m * BMT + erow0;
   long rm[2];                                                    // residual pixel of the two items (clamped)
   unsigned so[2];                                                // byte offset of the two items in `out`, 0xFFFFFFFF past the end
@@ -433,8 +401,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   for (int it = 0; it < 2; ++it) {
     const long m = em0 + 16 * it;
     rm[it] = m < p.M ? m : (long)p.M - 1;
-    if (FCP_ABLATE(p, 2)) rm[it] = 0;
-    so[it] = (m < p.M && !FCP_ABLATE(p, 1)) ? (unsigned)(m * p.out_ld * 4 + eq * 16) : 0xFFFFFFFFu;
+    so[it] = (m < p.M) ? (unsigned)(m * p.out_ld * 4 + eq * 16) : 0xFFFFFFFFu;
   }
   __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
@@ -458,18 +425,11 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
       rlo[it] = *reinterpret_cast<const u32x4_t*>(pb + 64);
     }
   };
-  const int nch = FCP_ABLATE(p, 8) ? 0 : NCH;
+  const int nch = NCH;
   f16x8 pch[2], pcl[2];                                          // rotated loop: T3 fragments of the previous chunk, per k-half
   f16x8 wx[ROT ? TN3 : 1], wy[ROT ? TN3 : 1];                    // rotated loop: conv1' fragments of the previous chunk's slice
-#ifdef FCP_CHAIN_REG_EPI
-  // this lane's eight conv3 channels of chunk 0 (channel group eq): scale and bias, requested a chunk ahead like the residual
-  f32x4 ws8a = *reinterpret_cast<const f32x4*>(p.ws3 + 8 * eq), ws8b = *reinterpret_cast<const f32x4*>(p.ws3 + 8 * eq + 4);
-  f32x4 b8a = *reinterpret_cast<const f32x4*>(p.b3 + 8 * eq), b8b = *reinterpret_cast<const f32x4*>(p.b3 + 8 * eq + 4);
-  constexpr int NCONST = 4;                                      // constant loads per chunk and thread (vmcnt bookkeeping below)
-#else
   float ws_l = p.ws3[l31], b_l = p.b3[l31];                      // this lane's conv3 channel of chunk 0 (MFMA layout: col = lane & 31)
   constexpr int NCONST = 2;
-#endif
   f16x8 ah[CS][2], al[CS][2];                                    // phase-2 A fragments: the wave's own 32 rows of T2, [slice][k-half]
   auto read_a2 = [&]() {
 #pragma unroll
@@ -496,15 +456,8 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   if (nch > 0) load_res(0);
   __builtin_amdgcn_sched_barrier(0);
 
-#ifdef FCP_CHAIN_PROBE   // cycle attribution of the chunk loop (experiment builds): workgroup 0, lane 0 of each wave
-  unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
-#define CPROBE(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); pc[k] += t_ - pt; pt = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define CPROBE(k) do { } while (0)
-#endif
   for (int j = 0; j < nch; ++j) {
     const bool more = j + 1 < NCH;
-    CPROBE(5);
     // ---- top: this chunk's filters have landed (everything younger may fly), every wave is done with chunk j - 1
     // (W1DB false: group j was issued at top(j-1) and already forced by the wait in front of phase 3 of chunk j-1; the
     //  ops younger than that wait — c(j), R(j), S(j-1) — may all stay in flight, which is the same count)
@@ -513,7 +466,6 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    CPROBE(0);
     if constexpr (!SPREAD) {
       if (more) dma_w3(j + 1, (j + 1) & 1);
       if constexpr (W1DB) {
@@ -524,7 +476,6 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    CPROBE(1);
     // ---- phase 2 operands: T2 (A: the wave's own 32 rows, the same for every chunk — read once, kept in registers) and
     //      filter group j (B), all K slices
     const char* b2base = lds + W3B_OFF + (j & 1) * W3CH + l31 * ROWB;
@@ -597,15 +548,9 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
         constexpr int q = decltype(tc)::value / 2, s = decltype(tc)::value % 2, sl = g * BG + q, trip = 2 * sl + s;
         static_for<0, 3>([&](auto ec) {
           constexpr int term = decltype(ec)::value;
-#ifdef FCP_CHAIN_REG_EPI   // transposed tile (filters x pixels: same products, same K order, same bits) for the register epilogue
-          if constexpr (term == 0) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[g & 1][q][s], al[sl][s], acc2, 0, 0, 0);
-          else if constexpr (term == 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[g & 1][q][s], ah[sl][s], acc2, 0, 0, 0);
-          else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[g & 1][q][s], ah[sl][s], acc2, 0, 0, 0);
-#else
           if constexpr (term == 0) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
           else if constexpr (term == 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bl[g & 1][q][s], acc2, 0, 0, 0);
           else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sl][s], bh[g & 1][q][s], acc2, 0, 0, 0);
-#endif
           if constexpr (ROT) {
             __builtin_amdgcn_sched_barrier(0);
             if (prev) static_for<0, PQ>([&](auto pc) { p3_step(std::integral_constant<int, (3 * trip + term) * PQ + decltype(pc)::value>{}); });
@@ -625,40 +570,9 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
         static_assert(PER <= 2, "at most two DMA instructions per MFMA triple");
       });
     });
-    CPROBE(2);
     // ---- acc2 * ws3 + b3 (per lane: one channel) -> the wave's rows of the fp32 tile.  Channel group q of a row is
     //      stored in the two 16-byte pieces the split32 image of that group will occupy (hi piece q ^ sw, lo piece
     //      (4 + q) ^ sw), so the epilogue rewrites each item in place.
-#ifdef FCP_CHAIN_REG_EPI
-    // ---- register epilogue (round 3): three lane permutations per accumulator register (v_permlane32_swap on the quads, then
-    //      v_permlane32_swap + v_permlane16_swap) leave lane (l & 15, l >> 4) with channels 8 eq .. 8 eq + 7 of rows
-    //      erow0 (va) and erow0 + 16 (vb); acc * ws3 + b3 below is the expression the staged form applied per channel.
-    //      No fp32 tile, no read-back: the staged form's round trip through LDS was 3-6 % of the chain launches
-    //      (an ablation bounded it).  Experiment builds only (FCP_CHAIN_REG_EPI): measured SLOWER than the staged form —
-    //      chains 1315 -> 1397 us, 128-wide pair 513 -> 565, layer-3 pair 443 -> 476 (tools/chain_epi_ab.sh): 24 lane permutations and
-    //      eight-channel constants per chunk cost more than 16 four-byte LDS writes and four 16-byte reads of the wave's own rows.
-    float va[8], vb[8];
-    {
-      auto swap32 = [](float& x, float& y) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-        const unsigned r0 = r[0], r1 = r[1];
-        x = __uint_as_float(r0); y = __uint_as_float(r1);
-      };
-      auto swap16 = [](float& x, float& y) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-        const unsigned r0 = r[0], r1 = r[1];
-        x = __uint_as_float(r0); y = __uint_as_float(r1);
-      };
-      static_for<0, 4>([&](auto ec) {
-        constexpr int e = decltype(ec)::value;
-        float q0 = acc2[e], q1 = acc2[4 + e], q2 = acc2[8 + e], q3 = acc2[12 + e];      // (named floats: see fcp_conv_f16x3_big.hip)
-        swap32(q0, q1); swap32(q2, q3);
-        swap32(q0, q2); swap16(q0, q2);
-        swap32(q1, q3); swap16(q1, q3);
-        va[e] = q0; va[4 + e] = q1; vb[e] = q2; vb[4 + e] = q3;
-      });
-    }
-#else
     {
       const int q = l31 >> 3;
 #pragma unroll
@@ -668,7 +582,6 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
         *reinterpret_cast<float*>(lds + CT_OFF + row * ROWB + (piece << 4) + (l31 & 3) * 4) = acc2[rr] * ws_l + b_l;
       }
     }
-#endif
     // ---- epilogue of conv3 for this chunk (own rows: LDS accesses of one wave execute in order, no barrier):
     //      out = relu(. + x) -> registers (stored in phase 3) and T3 (in place)
     __builtin_amdgcn_sched_barrier(0);
@@ -680,18 +593,9 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
       const int row = erow0 + 16 * it;
       const int sw = swz(row);
       char* crow = lds + CT_OFF + row * ROWB;
-#ifdef FCP_CHAIN_REG_EPI
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = (it ? vb[e] : va[e]) * ws8a[e] + b8a[e];
-        v[4 + e] = (it ? vb[4 + e] : va[4 + e]) * ws8b[e] + b8b[e];
-      }
-#else
       const f32x4 a = *reinterpret_cast<const f32x4*>(crow + ((eq ^ sw) << 4));
       const f32x4 b = *reinterpret_cast<const f32x4*>(crow + (((4 + eq) ^ sw) << 4));
       float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#endif
       float r[8];
       if constexpr (HAS_RES) join8(rhi[it], rlo[it], r);
 #pragma unroll
@@ -706,21 +610,14 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
       *reinterpret_cast<u32x4_t*>(crow + (((4 + eq) ^ sw) << 4)) = olo[it];
     }
     __builtin_amdgcn_sched_barrier(0);
-    CPROBE(3);
     asm volatile("" ::: "memory");
     if (more) {                                                  // a chunk ahead: the lane's channel constants, the residual
-#ifdef FCP_CHAIN_REG_EPI
-      ws8a = *reinterpret_cast<const f32x4*>(p.ws3 + (j + 1) * 32 + 8 * eq); ws8b = *reinterpret_cast<const f32x4*>(p.ws3 + (j + 1) * 32 + 8 * eq + 4);
-      b8a = *reinterpret_cast<const f32x4*>(p.b3 + (j + 1) * 32 + 8 * eq); b8b = *reinterpret_cast<const f32x4*>(p.b3 + (j + 1) * 32 + 8 * eq + 4);
-#else
       ws_l = p.ws3[(j + 1) * 32 + l31];
       b_l = p.b3[(j + 1) * 32 + l31];
-#endif
       load_res(j + 1);
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    CPROBE(4);
     if constexpr (!W1DB) {                                       // single conv1' buffer: slice j was issued at the top
       if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCONST + NRES) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -782,12 +679,6 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-#ifdef FCP_CHAIN_PROBE
-  CPROBE(5);
-  if (blockIdx.x == 0 && lane == 0)
-    printf("wave %d: %d chunks; wait+barrier %llu, filter DMA issue %llu, phase 2 %llu, epilogue %llu, scale/residual loads %llu, phase 3 + stores %llu\n",
-           wave, nch, pc[0], pc[1], pc[2], pc[3], pc[4], pc[5]);
-#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
@@ -911,12 +802,6 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   k.n = d->n; k.h = d->h; k.w = d->w; k.M = (int)M;
   static const int nt_env = getenv("FCP_NT_STORE") ? atoi(getenv("FCP_NT_STORE")) : 1;
   k.nt_store = nt_env;
-#ifdef FCP_CONV_PROFILING
-  static const int ablate_env = getenv("FCP_CHAIN_ABLATE") ? atoi(getenv("FCP_CHAIN_ABLATE")) : 0;
-  k.ablate = ablate_env;
-#else
-  k.ablate = 0;
-#endif
   hipStream_t s = (hipStream_t)stream;
   // tile height: 128 pixels / 4 waves (two independent workgroups per CU drift against each other: one's MFMAs beside the
   // other's epilogue); d->tile_m = 256 asks for the 8-wave form where the operand tile fits LDS and two waves per SIMD fit

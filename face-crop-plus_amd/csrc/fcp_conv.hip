@@ -207,9 +207,9 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
     for (int pp = 0; pp < 4; ++pp) {
       f32x4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + (FCP_ABLATE(p, 4) ? 0 : i * 32 * LDK + koff[pp]));
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + (i * 32 * LDK + koff[pp]));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + (FCP_ABLATE(p, 4) ? 0 : j * 32 * LDK + koff[pp]));
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + (j * 32 * LDK + koff[pp]));
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -223,13 +223,13 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
   // park slice kt+1 (other set) in the LDS buffer slice kt-1 just vacated
   auto step = [&](int kt, f32x4 (&ra_ld)[A_LD], f32x4 (&rb_ld)[B_LD], const f32x4 (&ra_st)[A_LD],
                   const f32x4 (&rb_st)[B_LD]) {
-    if (kt + 2 < p.ktiles && !FCP_ABLATE(p, 1)) {
+    if (kt + 2 < p.ktiles) {
       advance();
       load_slice(ra_ld, rb_ld, kt + 2, kh_i, kw_i, c0);
     }
     compute(kt & 1);
-    if (kt + 1 < p.ktiles && !FCP_ABLATE(p, 2)) store_slice(ra_st, rb_st, (kt + 1) & 1);
-    if (!FCP_ABLATE(p, 8)) __syncthreads();
+    if (kt + 1 < p.ktiles) store_slice(ra_st, rb_st, (kt + 1) & 1);
+    __syncthreads();
   };
 
   if (BUF) set_tap(0, 0, 0);
@@ -348,12 +348,6 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   k.vec_ok = (d->out_ld % 4 == 0) && (((uintptr_t)d->out & 15) == 0);
   if (d->res1) k.vec_ok = k.vec_ok && (d->res1_ld % 4 == 0) && (((uintptr_t)d->res1 & 15) == 0);
   if (d->res2) k.vec_ok = k.vec_ok && (d->res2_ld % 4 == 0) && (((uintptr_t)d->res2 & 15) == 0);
-#ifdef FCP_CONV_PROFILING
-  static const int ablate_env = getenv("FCP_CONV_ABLATE") ? atoi(getenv("FCP_CONV_ABLATE")) : 0;
-  k.ablate = ablate_env;
-#else
-  k.ablate = 0;
-#endif
   static const int nt_env = getenv("FCP_NT_STORE") ? atoi(getenv("FCP_NT_STORE")) : 1;
   k.nt_store = nt_env;
   k.balance = (d->flags & FCP_CONV_BALANCE_TAIL) ? 1 : 0;
@@ -388,12 +382,7 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
     k.w_bytes = (unsigned)w_bytes;
     // split32 activations: both operands are pure byte copies -> LDS-DMA kernel
     // two LDS stages (three were measured slower: they cost an occupancy step); profiling builds may override
-#ifdef FCP_CONV_PROFILING
-    static const int dma_env = getenv("FCP_CONV_DMA") ? atoi(getenv("FCP_CONV_DMA")) : 2;
-    const int dma_stages = dma_env == 3 ? 3 : 2;
-#else
     const int dma_stages = 2;
-#endif
     if (halo) {
       k.grid_n = 1;
       const unsigned long out_bytes = (unsigned long)M * d->out_ld * 4ul;

@@ -8,22 +8,12 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Profiling knobs (FCP_CONV_ABLATE bit mask: skip loads / stores / barriers to attribute time) exist only in
-// builds made with FCP_BUILD_PROFILING=1 (-DFCP_CONV_PROFILING); production kernels carry none of them.
-#ifdef FCP_CONV_PROFILING
-#define FCP_ABLATE(p, bits) ((p).ablate & (bits))
-#else
-#define FCP_ABLATE(p, bits) 0
-#endif
 
-// Cache policy of the LDS-DMA operand loads (the `aux` immediate of raw.ptr.buffer.load.lds on gfx950: 1 = sc0,
-// 2 = nt, 16 = sc1): activations (A) and filters (B) separately; experiment builds override them.
-#ifndef FCP_AUX_A
-#define FCP_AUX_A 0
-#endif
-#ifndef FCP_AUX_B
-#define FCP_AUX_B 0
-#endif
+// Cache policy of the LDS-DMA operand loads (the `aux` immediate of raw.ptr.buffer.load.lds on gfx950: 1 = sc0, 2 = nt,
+// 16 = sc1), activations (A) and filters (B): default policy for both — nt / sc1 on either operand measured equal or slower
+// (profiles/r03_probes.md section 1).
+constexpr int FCP_AUX_A = 0;
+constexpr int FCP_AUX_B = 0;
 
 namespace fcp_conv {
 
@@ -47,7 +37,6 @@ struct ConvK {
   unsigned in_bytes, w_bytes;
   const float* wscale;  // per-cout power-of-two filter scale (fp16x3 path) or nullptr
   int in_fmt, out_fmt, res1_fmt, res2_fmt;   // 0 = fp32 NHWC, 1 = split32 (see fcp_hip.h)
-  int ablate;  // FCP_CONV_ABLATE in profiling builds, otherwise 0 and never read
   // second source of a 1x1 conv (channels >= csplit), LDS-DMA kernels only; in2 == nullptr: off
   const float* in2;
   unsigned in2_bytes;
@@ -246,14 +235,8 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4_t
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const unsigned hu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]));
-#ifdef FCP_NO_FMA_MIX
-    const auto h2 = __builtin_bit_cast(f16x2_t, hu);
-    const float r0 = x[2 * q] - (float)h2[0];
-    const float r1 = x[2 * q + 1] - (float)h2[1];
-#else
     const float r0 = fcp_mix_diff<0>(x[2 * q], hu);
     const float r1 = fcp_mix_diff<1>(x[2 * q + 1], hu);
-#endif
     hi[q] = hu;
     lo[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
   }
@@ -263,15 +246,8 @@ __device__ __forceinline__ void join8(const u32x4_t& hi, const u32x4_t& lo, floa
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const unsigned hu = hi[q], lu = lo[q];
-#ifdef FCP_NO_FMA_MIX
-    const f16x2_t h = __builtin_bit_cast(f16x2_t, hu);
-    const f16x2_t l = __builtin_bit_cast(f16x2_t, lu);
-    x[2 * q] = (float)h[0] + (float)l[0];
-    x[2 * q + 1] = (float)h[1] + (float)l[1];
-#else
     x[2 * q] = fcp_mix_sum<0>(hu, lu);
     x[2 * q + 1] = fcp_mix_sum<1>(hu, lu);
-#endif
   }
 }
 // byte offset of channel c (multiple of 8) inside a split32 pixel: group (c/32)*128 B, hi at (c%32)*2, lo +64
@@ -509,7 +485,6 @@ __device__ __forceinline__ void conv_epilogue8(const ConvK& p, f32x16 (&acc)[TM]
       if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
       v[e] = x;
     }
-    if (FCP_ABLATE(p, 64)) continue;   // profiling builds only: no output stores
     if (p.out_fmt == 1) {
       u32x4_t hi, lo;
       split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);

@@ -140,9 +140,6 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   };
   // one slice: A_LD + B_LD DMA instructions per wave, each 64 lanes x 16 B = rows 8*wave + 64*i .. +7
   auto dma_slice = [&](int kt, int stage) {
-#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 1)      // experiment builds (wrong results): no DMA after the prologue
-    if (kt >= 2) return;
-#endif
     char* a = lds + stage * STAGE + wave_u * 8 * ROWB;
     char* b = a + BMB * ROWB;
     if (c0 >= p.csplit) {                  // wave-uniform: this slice comes from the second source
@@ -155,11 +152,7 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     } else {
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
-#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 4)      // activation DMA issued out of range: zero fill, no memory traffic
-        const unsigned ro = kt >= 2 ? 0xFFFFFFFFu : rowoff[i];
-#else
         const unsigned ro = rowoff[i];
-#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(a + 64 * i * ROWB), 16,
                                                  (int)(ro == 0xFFFFFFFFu ? 0xFFFFFFFFu : ro + (unsigned)(c0 * 4)), 0, 0, FCP_AUX_A);
       }
@@ -167,11 +160,7 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(b + 64 * i * ROWB), 16,
-#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 8)      // filter DMA out of range
-                                               (int)(kt >= 2 ? 0xFFFFFFFFu : woff[i] + (unsigned)(kt * BK * 4)), 0, 0, FCP_AUX_B);
-#else
                                                (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, FCP_AUX_B);
-#endif
   };
 
   f32x16 acc[TM][TN];
@@ -234,24 +223,17 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     static_for<0, NM>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       constexpr int g = m / (TMA * TN), i = (m % (TMA * TN)) / TN, j = m % TN;
-#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 2)
-      asm volatile("" : "+v"(acc[i][j]) : "v"(fal[cs][i]), "v"(fah[cs][i]), "v"(fbh[cs][j]), "v"(fbl[cs][j]));
-#else
       // the filter fragment is the ROW operand: the tile is accumulated transposed (filters x pixels; same products, same
       // K order, same bits), so that a lane ends up with four consecutive filters of ONE pixel per accumulator quad —
       // what the LDS-free epilogue below needs
       if constexpr (g == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[cs][j], fal[cs][i], acc[i][j], 0, 0, 0);
       else if constexpr (g == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbl[cs][j], fah[cs][i], acc[i][j], 0, 0, 0);
       else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[cs][j], fah[cs][i], acc[i][j], 0, 0, 0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
       // read r is issued after MFMA floor((r + 1) * NM / NR) - 1
       static_for<0, NR>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         if constexpr (((r + 1) * NM) / NR - 1 == m
-#if defined(FCP_BIG_ABLATE) && (FCP_BIG_ABLATE & 16)     // no fragment reads in the loop
-                      && false
-#endif
         ) {
           if constexpr (r < 2 * TMA) {
             constexpr int ii = r / 2;
@@ -272,23 +254,15 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 
-#ifdef FCP_BIG_PROBE   // cycle attribution (experiment builds): workgroup 0, lane 0 of each wave, printed at exit
-  unsigned long long pc[4] = {0, 0, 0, 0}, pt = __builtin_readcyclecounter();
-#define BPROBE(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); pc[k] += t_ - pt; pt = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define BPROBE(k) do { } while (0)
-#endif
   unsigned sx = 0u;                       // XOR of the stage holding slice kt
   for (int kt = 0; kt < p.ktiles; ++kt) {
     // ---- k-half 0 of slice kt on the matrix pipe, k-half 1 on its way to registers
     mfmas_reads(SET0, SET1, sx);
     __builtin_amdgcn_sched_barrier(0);
-    BPROBE(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's part of slice kt+1 has landed
     __builtin_amdgcn_s_barrier();                          // slice kt+1 visible; nobody reads slice kt's stage again
     __builtin_amdgcn_sched_barrier(0);
-    BPROBE(1);
     // ---- k-half 1 of slice kt (k-half 0 of slice kt+1 on its way to registers), and the DMA of slice kt+2 into the
     //      stage that has just died.  An LDS-DMA instruction holds its wave until the vector-memory path has taken the
     //      64 requests: with all eight waves issuing their A_LD + B_LD instructions at once (64 KiB per slice through a
@@ -303,7 +277,6 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
       dma_slice(kt + 2, kt & 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    BPROBE(2);
     mfmas_reads(SET1, SET0, sx ^ (unsigned)STAGE);
     __builtin_amdgcn_sched_barrier(0);
     if (!dma_first && kt + 2 < p.ktiles) {
@@ -313,14 +286,8 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    BPROBE(3);
     sx ^= (unsigned)STAGE;
   }
-#ifdef FCP_BIG_PROBE
-  if (blockIdx.x == 0 && lane == 0)
-    printf("wave %d: %d slices; k-half 0 (reads+mfma) %llu, wait+barrier %llu, reads+dma issue %llu, k-half 1 mfma %llu\n", wave_u, p.ktiles,
-           pc[0], pc[1], pc[2], pc[3]);
-#endif
   };
   for (;;) {
   // slices 0 and 1 of this tile have landed (and, from the second tile on, the previous tile's stores have left)

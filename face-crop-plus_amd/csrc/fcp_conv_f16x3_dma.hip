@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : 3)) conv_igemm_f16x3_dma
   __builtin_amdgcn_s_barrier();
 
   int stage = 0;
-  const int kt_end = FCP_ABLATE(p, 128) ? 0 : p.ktiles;   // profiling builds only: skip the main loop
+  const int kt_end = p.ktiles;
   for (int kt = 0; kt < kt_end; ++kt) {
     const char* Ab = lds + stage * STAGE + aoff;
     const char* Bb = lds + stage * STAGE + boff;

@@ -379,13 +379,6 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-#ifdef FCP_HALO_PROBE   // cycle attribution of workgroup 0 / each compute wave's lane 0 (experiment builds): printed at exit
-  unsigned long long pc[5] = {0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
-  const unsigned long long pstart = pt;
-#define PROBE(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); pc[k] += t_ - pt; pt = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PROBE(k) do { } while (0)
-#endif
   // ---- main loop over the stream of blocks (slice, pass): nine unrolled taps each
   int blk = 0;                                          // block index inside the current tile
   unsigned bbuf = 0, astage = 0;                        // filter buffer of the current block, halo stage of the current slice
@@ -396,16 +389,12 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
     const bool last_of_tile = blk == nblocks - 1;
     const int nit = it + slots, ntile = xcd * per_x + nit;
     const bool more = nit < per_x && ntile < ntiles;
-    PROBE(4);
     static_for<0, 8>([&](auto tc) { tap_step(tc, pass_c, aoff, boff); });
-    PROBE(0);
     // tap 8's fragments are (about to be) in registers: the block's buffer (and, after the last pass, the slice's
     // stage) is dead for this wave; the loaders arrive when the next block's operands are in LDS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    PROBE(1);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    PROBE(2);
     const unsigned aoff_next = new_slice ? (astage ^ 1u) * (unsigned)A_BYTES : aoff;
     const unsigned boff_next = (bbuf ^ 1u) * (unsigned)B_BYTES;
     // (after the workgroup's very last block the "next block" reads fetch stale LDS contents that nothing consumes:
@@ -418,14 +407,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
     if constexpr (new_slice) {
       if (last_of_tile) {
         __builtin_amdgcn_sched_barrier(0);
-        PROBE(4);
         epilogue((int)freed);
-        PROBE(3);
-#ifdef FCP_HALO_PROBE
-        if (!more && blockIdx.x == 0 && lane == 0)
-          printf("wave %d: total %llu cycles; taps0-7 %llu, lgkm wait %llu, barrier %llu, epilogue %llu, rest (tap 8) %llu\n", wave_u,
-                 __builtin_readcyclecounter() - pstart, pc[0], pc[1], pc[2], pc[3], pc[4]);
-#endif
         if (!more) return true;
         it = nit;
         blk = 0;
@@ -873,9 +855,7 @@ int launch_f16x3_halo(const ConvK& k, hipStream_t s) {
   return 0;
 }
 
-#ifndef FCP_WIDE2_BT
 #define FCP_WIDE2_BT 2
-#endif
 constexpr int WIDE2_BT = FCP_WIDE2_BT;   // taps per barrier of the 64-filter form (eight 8 KB slots); tools/wide2_ab.sh: RRDB conv5 610 / 586 / 605 us for 1 / 2 / 3
 
 int launch_f16x3_halo_wide(const ConvK& k, hipStream_t s) {

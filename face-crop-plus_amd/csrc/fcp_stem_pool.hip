@@ -167,24 +167,13 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
     abase_t[k] = (2 * si) * IPITCH + 6 * sj;
   }
 
-#ifdef FCP_STEM_PROBE   // cycle attribution of the patch loop (experiment builds): workgroup 0, lane 0 of each wave
-  unsigned long long pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
-  int npatch_done = 0;
-#define SPROBE(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); pc[k] += t_ - pt; pt = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define SPROBE(k) do { } while (0)
-#endif
   int patch = blockIdx.x;
   if (patch < p.npatches) fetch(patch);
   for (; patch < p.npatches; patch += gridDim.x) {
-    SPROBE(8);
     commit();
-    SPROBE(0);
     lds_barrier();                                      // image patch visible
-    SPROBE(1);
     const int next = patch + gridDim.x;
     if (next < p.npatches) fetch(next);                 // global loads of the next patch fly under the MFMAs
-    SPROBE(2);
 
     const int pxi = patch % p.tiles_x;
     const int pyi = (patch / p.tiles_x) % p.tiles_y;
@@ -211,10 +200,6 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
         const u32x4_t raw = {wp[0], wp[1], wp[2], wp[3]};
         return __builtin_bit_cast(f16x8, raw);
       };
-#ifdef FCP_STEM_ABLATE_AREAD   // experiment: no A-fragment LDS reads (wrong results)
-      auto afrag2 = [&](int q) { return wh[q]; };
-#define afrag afrag2
-#endif
       f16x8 a = afrag(0);
 #pragma unroll
       for (int q = 0; q < KSTEPS; ++q) {
@@ -225,13 +210,6 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q], a, acc, 0, 0, 0);
         a = an;
       }
-#ifdef FCP_STEM_ABLATE_AREAD
-#undef afrag
-#endif
-#ifdef FCP_STEM_ABLATE_STAGE  // experiment: one staged value per tile instead of 16 (wrong results)
-      if (acc[0] + acc[5] + acc[10] + acc[15] == 12345.f) stage[tid] = acc[3];
-      continue;
-#endif
       // raw accumulators -> stage.  The tile was computed transposed (filters x pixels): a lane holds ONE stem pixel
       // (lane & 31) and filters 8 g + 4 half + 0..3 of its column tile, i.e. four 16-byte staging writes per tile instead
       // of sixteen 4-byte ones, one validity test per lane.  Scale (> 0), bias and ReLU are monotone per channel, so they
@@ -253,9 +231,7 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
         }
       }
     }
-    SPROBE(3);
     lds_barrier();                                      // stem tile staged; image patch no longer read
-    SPROBE(4);
 
     // HAS_C1: conv1's filter fragments (8 x 16 B per lane, L1-resident) are requested here, a pooling pass ahead of use
     f16x8 c1w[8];
@@ -314,7 +290,6 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
         }
       }
     }
-    SPROBE(5);
     if constexpr (HAS_C1) {
       lds_barrier();                                    // conv1 operand complete; the stem stage is no longer read
       // INVARIANT: c1in rows of pooled pixels outside the image (and rows 80..95) are never written and hold stale LDS —
@@ -367,18 +342,8 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
         }
       }
     }
-    SPROBE(6);
     lds_barrier();                                      // stage free for the next patch
-    SPROBE(7);
-#ifdef FCP_STEM_PROBE
-    ++npatch_done;
-#endif
   }
-#ifdef FCP_STEM_PROBE
-  if (blockIdx.x == 0 && lane == 0)
-    printf("wave %d: %d patches; commit %llu, barrier %llu, fetch issue %llu, MFMAs + stage %llu, barrier %llu, pool + stores %llu, conv1 %llu, barrier %llu, loop %llu\n",
-           wave, npatch_done, pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], pc[6], pc[7], pc[8]);
-#endif
 }
 
 }  // namespace

@@ -2,9 +2,12 @@
 # GPU box: joule ledger of the conv kernel classes.  For every build variant each class runs alone in
 # a steady loop for $SECS s while rocm-smi samples socket power / sclk (tools/smi_loop.sh); J per launch = W x us.
 #   bash tools/ledger.sh > gpurun_out/r4_ledger.txt
-# Variants are experiment builds made in the box's scratch copy of the repo (wrong results by construction); the product
-# library is rebuilt at the end.
+# Variants are experiment builds made in the box's scratch copy of the repo (wrong results by construction): the ablation
+# switches are NOT part of the product kernels any more — tools/probes/experiment_switches_r04.patch re-adds them to the
+# scratch copy (it is the reverse of the round-4 clean-up commit), and the product sources + library are restored at the end.
 cd $GRAFT_REPO_ROOT
+cp -r face-crop-plus_amd/csrc /tmp/csrc.product
+patch -p1 -s < tools/probes/experiment_switches_r04.patch || { echo "patch failed"; exit 1; }
 KERNELS=${KERNELS:-"chain pair2 pair3 big3x3 big1x1 dma1x1 dma3x3s2 wide halo stem copy"}
 build() { env "$@" python face-crop-plus_amd/build_native.py --force > /tmp/ledger_build.log 2>&1 || { echo "BUILD FAILED: $*"; tail -5 /tmp/ledger_build.log; }; }
 run() {   # label, env assignments...
@@ -17,7 +20,7 @@ build FCP_X=0
 run "full (product build)" FCP_X=0
 build FCP_BUILD_FLAGS="-include tools/probes/fcp_no_mfma.h"
 run "no MFMA (every f16 MFMA an empty asm statement; all data movement kept)" FCP_X=0
-build FCP_BUILD_PROFILING=1
+build FCP_BUILD_DEFINES="FCP_CONV_PROFILING"
 run "profiling build, nothing ablated (control)" FCP_X=0
 KERNELS="chain pair2 pair3" run "chain: no out stores" FCP_CHAIN_ABLATE=1
 KERNELS="chain pair2 pair3" run "chain: no residual loads" FCP_CHAIN_ABLATE=2
@@ -32,3 +35,4 @@ KERNELS="big3x3 big1x1" run "256-row: no fragment reads in the loop" FCP_X=0
 build FCP_BUILD_DEFINES="FCP_BIG_ABLATE=17"
 KERNELS="big3x3 big1x1" run "256-row: MFMAs only (no DMA, no fragment reads)" FCP_X=0
 build FCP_X=0
+rm -rf face-crop-plus_amd/csrc && cp -r /tmp/csrc.product face-crop-plus_amd/csrc   # product sources and library back
