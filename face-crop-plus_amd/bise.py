@@ -50,7 +50,44 @@ class BiSeNet:
         with torch.cuda.device(device), E.default_precision(precision):
             self._p = self._pack(sd, device)
         self.precision = E.resolve_precision(precision)
+        if self.precision == 1 and E.selfcheck_mode(weights):
+            self.selfcheck(sd)
         return self
+
+    @torch.no_grad()
+    def selfcheck(self, sd=None, faces_u8: torch.Tensor | None = None, rel_tol: float = 1e-4):
+        """Range / accuracy guard of the fp16x3 path (see ``RetinaFace.selfcheck``): two calibration crops through the
+        network with a max-|x| reduction behind every conv launch (``FloatingPointError`` at 2^15), and — with the state
+        dict — the 1/8-resolution class logits against an exact-fp32 twin."""
+        if self.precision != 1:
+            self.selfcheck_report = {"skipped": "exact-fp32 path: nothing to guard"}
+            return self.selfcheck_report
+        dev = self.device
+        with torch.cuda.device(dev):
+            if faces_u8 is None:
+                g = torch.Generator(device="cpu").manual_seed(20260928)
+                ramp = (torch.arange(256)[:, None] // 2 + torch.arange(256)[None, :] // 2).to(torch.uint8)
+                faces_u8 = torch.stack([torch.randint(0, 256, (256, 256, 3), generator=g, dtype=torch.uint8),
+                                        ramp[..., None].expand(256, 256, 3).contiguous()])
+            faces_u8 = faces_u8.to(dev).contiguous()
+            f, h, w, _ = faces_u8.shape
+            x4 = E.Act.empty(f, 512, 512, 4, dev)
+            N.check(N.lib().fcp_bise_preprocess_u8(N.ptr(faces_u8), f, h, w, x4.ptr(), 512, 512, (C.c_float * 3)(*self.mean),
+                                                   (C.c_float * 3)(*self.std), N.stream_ptr()), "fcp_bise_preprocess_u8")
+            tuning, E.Autotune.enabled = E.Autotune.enabled, False
+            try:
+                with E.RangeMonitor() as mon:
+                    lg = self.forward_logits8(x4)
+                rep = {"launch_absmax": mon.check("BiSeNet"), "limit": E.RangeMonitor.LIMIT, "logit_rel_diff": None}
+                if sd is not None:
+                    twin = BiSeNet(self.attr_groups, self.mask_groups, self.batch_size).load(dev, sd, "f32")
+                    ref = twin.forward_logits8(x4)
+                    rep["logit_rel_diff"] = E.selfcheck_compare("BiSeNet logits", lg.buf[..., :NUM_CLASSES],
+                                                                ref.buf[..., :NUM_CLASSES], rel_tol)
+            finally:
+                E.Autotune.enabled = tuning
+        self.selfcheck_report = rep
+        return rep
 
     @staticmethod
     def _pack(sd, dev):

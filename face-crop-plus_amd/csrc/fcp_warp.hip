@@ -117,6 +117,17 @@ __device__ __forceinline__ int border_interp(int p, int len, int border) {
   return -1;  // constant
 }
 
+// Six consecutive bytes (two RGB pixels) at byte offset `off` of `base`: one aligned 12-byte load + a funnel shift
+// instead of six byte loads.  The caller guarantees that (off & ~3) + 12 stays inside the allocation.
+__device__ __forceinline__ unsigned long long load6(const uint8_t* __restrict__ base, long off) {
+  const long a = off & ~3L;
+  const unsigned sh = (unsigned)(off & 3) * 8u;
+  const unsigned* q = reinterpret_cast<const unsigned*>(base + a);
+  const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
+  const unsigned long long lo = (unsigned long long)d0 | ((unsigned long long)d1 << 32);
+  return sh ? (lo >> sh) | ((unsigned long long)d2 << (64u - sh)) : lo;
+}
+
 template <int PX>
 __global__ void __launch_bounds__(256) warp_affine_kernel(
     const uint8_t* __restrict__ images, int n, int h, int w, const int* __restrict__ img_idx,
@@ -125,23 +136,19 @@ __global__ void __launch_bounds__(256) warp_affine_kernel(
   const int face = blockIdx.y;
   const int groups_per_row = (out_w + PX - 1) / PX;
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= groups_per_row * out_h) return;
-  const int y = g / groups_per_row;
-  const int x0 = (g - y * groups_per_row) * PX;
+  const bool active = g < groups_per_row * out_h;
+  const int y = active ? g / groups_per_row : 0;
+  const int x0 = active ? (g - y * groups_per_row) * PX : 0;
   uint8_t* dst = out + (((long)face * out_h + y) * out_w + x0) * 3;
   uint8_t px[PX * 3];
 #pragma unroll
   for (int q = 0; q < PX * 3; ++q) px[q] = 0;
 
-  const bool valid = ok == nullptr || ok[face] != 0;
-  if (valid) {
-    const int img = img_idx[face];
-    int pt = 0, pb = 0, pl = 0, pr = 0;
-    if (paddings != nullptr) { pt = paddings[img * 4]; pb = paddings[img * 4 + 1]; pl = paddings[img * 4 + 2]; pr = paddings[img * 4 + 3]; }
-    const int sh = h - pt - pb, sw = w - pl - pr;  // un-padded slice (cropper.py:538-539)
-    const long sstep = (long)w * 3;
-    const uint8_t* S0 = images + ((long)img * h + pt) * sstep + (long)pl * 3;
-    // invert the forward transform exactly like cv::warpAffine does
+  const bool valid = ok == nullptr || ok[face] != 0;       // uniform over the workgroup (one face per blockIdx.y)
+  // The inverse map is the same for every lane of the workgroup: one lane inverts the forward transform exactly like
+  // cv::warpAffine does (two double divisions), the others read it from LDS.
+  __shared__ double sM[6];
+  if (valid && threadIdx.x == 0) {
     double M[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) M[q] = mat[(long)face * 6 + q];
@@ -152,6 +159,23 @@ __global__ void __launch_bounds__(256) warp_affine_kernel(
     const double b1 = -M[0] * M[2] - M[1] * M[5];
     const double b2 = -M[3] * M[2] - M[4] * M[5];
     M[2] = b1; M[5] = b2;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) sM[q] = M[q];
+  }
+  __syncthreads();
+  if (!active) return;
+  if (valid) {
+    const int img = img_idx[face];
+    int pt = 0, pb = 0, pl = 0, pr = 0;
+    if (paddings != nullptr) { pt = paddings[img * 4]; pb = paddings[img * 4 + 1]; pl = paddings[img * 4 + 2]; pr = paddings[img * 4 + 3]; }
+    const int sh = h - pt - pb, sw = w - pl - pr;  // un-padded slice (cropper.py:538-539)
+    const long sstep = (long)w * 3;
+    const long s0off = ((long)img * h + pt) * sstep + (long)pl * 3;
+    const uint8_t* S0 = images + s0off;
+    const long total = (long)n * h * sstep;          // bytes of the batch: bound of the 12-byte loads
+    double M[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) M[q] = sM[q];
     const int X0 = (int)((unsigned)cv_round((M[1] * y + M[2]) * 1024.0) + 16u);
     const int Y0 = (int)((unsigned)cv_round((M[4] * y + M[5]) * 1024.0) + 16u);
     const int width1 = sw - 1 > 0 ? sw - 1 : 0, height1 = sh - 1 > 0 ? sh - 1 : 0;
@@ -169,7 +193,21 @@ __global__ void __launch_bounds__(256) warp_affine_kernel(
       const uint8_t *v0, *v1, *v2, *v3;
       const uint8_t zero[3] = {0, 0, 0};
       if ((unsigned)sx < (unsigned)width1 && (unsigned)sy < (unsigned)height1) {
-        v0 = S0 + sy * sstep + sx * 3; v1 = v0 + 3; v2 = v0 + sstep; v3 = v2 + 3;
+        const long o0 = s0off + sy * sstep + sx * 3, o1 = o0 + sstep;
+        if (((o1 & ~3L) + 12) <= total) {
+          // interior: the 2 x 2 neighbourhood is two runs of six bytes — two 12-byte loads instead of twelve byte loads
+          const unsigned long long r0 = load6(images, o0), r1 = load6(images, o1);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int a0 = (int)((r0 >> (8 * c)) & 255u), a1 = (int)((r0 >> (8 * c + 24)) & 255u);
+            const int a2 = (int)((r1 >> (8 * c)) & 255u), a3 = (int)((r1 >> (8 * c + 24)) & 255u);
+            const int acc = a0 * w0 + a1 * w1 + a2 * w2 + a3 * w3;
+            const int r = (acc + (1 << 14)) >> 15;
+            px[q * 3 + c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+          }
+          continue;
+        }
+        v0 = images + o0; v1 = v0 + 3; v2 = v0 + sstep; v3 = v2 + 3;
       } else {
         if (border == 0 && (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0)) continue;  // all-constant: 0
         int sx0, sx1, sy0, sy1;

@@ -415,6 +415,25 @@ class RangeMonitor:
         return rep
 
 
+def selfcheck_mode(weights) -> bool:
+    """Whether a model's ``load`` runs its range / accuracy self-check: FCP_SELFCHECK=1 always, 0 never; by default
+    ("auto") whenever the weights come from a checkpoint — a file, the hub cache or a download — i.e. are not this
+    package's own generated ones or a state dict the caller built in memory."""
+    mode = os.environ.get("FCP_SELFCHECK", "auto")
+    from_checkpoint = weights is None or (isinstance(weights, str) and weights != "generated")
+    return mode == "1" or (mode == "auto" and from_checkpoint)
+
+
+def selfcheck_compare(what: str, got: torch.Tensor, ref: torch.Tensor, rel_tol: float) -> float:
+    """max |got - ref| relative to the reference map's largest value (diagnostic arithmetic, not the data path)."""
+    scale = float(ref.abs().max().item())
+    diff = float((got - ref).abs().max().item()) / max(scale, 1e-30)
+    if not diff <= rel_tol:
+        raise FloatingPointError(f"{what}: the fp16x3 path and the exact-fp32 path disagree by {diff:.3g} of the output's "
+                                 f"largest value (tolerance {rel_tol:g}) with these weights; load with precision='f32'.")
+    return diff
+
+
 def _monitor(label, *outs):
     mon = RangeMonitor.active
     if mon is not None:

@@ -70,9 +70,7 @@ class RetinaFace:
         # Range / accuracy guard of the fp16x3 path (``selfcheck``): FCP_SELFCHECK=1 always, 0 never; by default ("auto")
         # whenever the weights come from a checkpoint — a file, the hub cache or a download — i.e. are not this package's
         # own generated ones or a state dict the caller built in memory.
-        mode = os.environ.get("FCP_SELFCHECK", "auto")
-        from_checkpoint = weights is None or (isinstance(weights, str) and weights != "generated")
-        if self.precision == 1 and (mode == "1" or (mode == "auto" and from_checkpoint)):
+        if self.precision == 1 and E.selfcheck_mode(weights):
             self.selfcheck(sd)
         return self
 
@@ -110,15 +108,8 @@ class RetinaFace:
                     with E.default_precision("f32"):
                         twin._p = self._pack(sd, dev)
                     ref = twin.forward_heads(E.u8_to_nhwc4(images_u8, sub=(123.0, 117.0, 104.0)))
-                    diffs = []
-                    for a, b in zip(heads, ref):
-                        scale = float(b.buf.abs().max().item())
-                        diffs.append(float((a.buf - b.buf).abs().max().item()) / max(scale, 1e-30))
-                    rep["head_rel_diff"] = diffs
-                    if not max(diffs) <= rel_tol:
-                        raise FloatingPointError(
-                            f"RetinaFace: the fp16x3 path and the exact-fp32 path disagree on the head maps by {max(diffs):.3g} "
-                            f"of their largest value (tolerance {rel_tol:g}) with these weights; load with precision='f32'.")
+                    rep["head_rel_diff"] = [E.selfcheck_compare("RetinaFace head maps", a.buf, b.buf, rel_tol)
+                                            for a, b in zip(heads, ref)]
             finally:
                 E.Autotune.enabled = tuning
         self.selfcheck_report = rep

@@ -56,7 +56,37 @@ class RRDBNet:
                           for t in range(self.NUM_BLOCKS)]
             self._p = p
         self.precision = E.resolve_precision(precision)
+        if self.precision == 1 and E.selfcheck_mode(weights):
+            self.selfcheck(sd)
         return self
+
+    @torch.no_grad()
+    def selfcheck(self, sd=None, image_u8: torch.Tensor | None = None, rel_tol: float = 1e-4):
+        """Range / accuracy guard of the fp16x3 path (see ``RetinaFace.selfcheck``): one small calibration image through the
+        351 convs with a max-|x| reduction behind every launch (``FloatingPointError`` at 2^15), and — with the state dict —
+        the x4 output against an exact-fp32 twin."""
+        if self.precision != 1:
+            self.selfcheck_report = {"skipped": "exact-fp32 path: nothing to guard"}
+            return self.selfcheck_report
+        dev = self.device
+        with torch.cuda.device(dev):
+            if image_u8 is None:
+                g = torch.Generator(device="cpu").manual_seed(20260928)
+                image_u8 = torch.randint(0, 256, (1, 48, 64, 3), generator=g, dtype=torch.uint8)
+                image_u8[0, :24] = (torch.arange(64)[None, :, None] * 4).clamp(max=255).to(torch.uint8)   # half ramp, half noise
+            x4 = E.u8_to_nhwc4(image_u8.to(dev).contiguous(), sub=(0.0, 0.0, 0.0), div=255.0)
+            tuning, E.Autotune.enabled = E.Autotune.enabled, False
+            try:
+                with E.RangeMonitor() as mon:
+                    y = self.forward(x4)
+                rep = {"launch_absmax": mon.check("RRDBNet"), "limit": E.RangeMonitor.LIMIT, "output_rel_diff": None}
+                if sd is not None:
+                    ref = RRDBNet(self.min_face_factor).load(dev, sd, "f32").forward(x4)
+                    rep["output_rel_diff"] = E.selfcheck_compare("RRDBNet x4 output", y.buf[..., :3], ref.buf[..., :3], rel_tol)
+            finally:
+                E.Autotune.enabled = tuning
+        self.selfcheck_report = rep
+        return rep
 
     def forward(self, x4: E.Act) -> E.Act:
         """NHWC4 image in [0,1] (n,h,w,4) -> (n,4h,4w,4) with the RGB output in channels 0..2."""

@@ -76,3 +76,29 @@ def test_selfcheck_runs_automatically_for_checkpoint_files(device, tmp_path, mon
     det = RetinaFace("largest", 0.6).load(device, str(tmp_path / "retinaface_detector.pth"))
     assert max(det.selfcheck_report["head_rel_diff"]) < 1e-4
     assert not hasattr(RetinaFace("largest", 0.6).load(device, sd), "selfcheck_report")
+
+
+def test_selfcheck_bisenet_and_rrdb(device):
+    """The same guard on the other two networks: generated weights pass (ranges far below 2^15, fp16x3 == exact fp32 to
+    1e-4 of the output's largest value); a blown-up BatchNorm scale / conv weight trips it."""
+    from face_crop_plus_amd import weights
+    from face_crop_plus_amd.bise import BiSeNet
+    from face_crop_plus_amd.rrdb import RRDBNet
+    sdb = weights.generate_state_dict("bisenet")
+    par = BiSeNet({"glasses": [6]}, None, 8).load(device, sdb)
+    rep = par.selfcheck(sdb)
+    assert len(rep["launch_absmax"]) >= 25 and all(0 < v < rep["limit"] for _, v in rep["launch_absmax"])
+    assert rep["logit_rel_diff"] < 1e-4
+    bad = dict(sdb)
+    bad["cp.resnet.layer3.0.bn2.weight"] = sdb["cp.resnet.layer3.0.bn2.weight"] * 1e5
+    with pytest.raises(FloatingPointError, match=r"BiSeNet.*2\^15"):
+        BiSeNet(None, {"eyes": [4, 5]}, 8).load(device, bad).selfcheck(bad)
+    sde = weights.generate_state_dict("rrdb")
+    enh = RRDBNet(0.001).load(device, sde)
+    rep = enh.selfcheck(sde)
+    assert len(rep["launch_absmax"]) >= 351 and all(v < rep["limit"] for _, v in rep["launch_absmax"])
+    assert rep["output_rel_diff"] < 1e-4
+    bad = dict(sde)
+    bad["RRDB_trunk.3.RDB2.conv3.weight"] = sde["RRDB_trunk.3.RDB2.conv3.weight"] * 1e6
+    with pytest.raises(FloatingPointError, match=r"RRDBNet.*2\^15"):
+        RRDBNet(0.001).load(device, bad).selfcheck(bad)
