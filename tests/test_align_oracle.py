@@ -199,3 +199,21 @@ def test_opencv_sequence_degenerate_inputs():
     assert m is not None and np.abs(m - A.estimate_transform(pts, tgt)).max() < 1e-8
     bad = tgt.copy(); bad[2, 0] = np.nan
     assert A.estimate_transform_cv_sequence(bad, tgt) is None
+
+
+def test_similarity_matches_scikit_image_umeyama():
+    """Third-party pin of row a13's similarity form: scikit-image 0.18.3's `SimilarityTransform.estimate` (Umeyama's
+    closed form, an independent implementation of the least-squares optimum OpenCV's estimator converges to) on 65
+    five-point sets of face-like geometry, coordinates up to 3000 px; fixture written by
+    tests/golden/make_golden_skimage.py under the image's /opt/conda python3.9 (OpenCV itself is not in the image)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage_similarity.npz"))
+    worst_abs = worst_rel = 0.0
+    for s, m in zip(z["est_src"], z["est_mat"]):
+        mine = A.estimate_transform(s, z["est_dst"], False)
+        assert mine is not None
+        worst_abs = max(worst_abs, float(np.abs(mine - m).max()))
+        worst_rel = max(worst_rel, float(np.abs(mine - m).max() / np.abs(m).max()))
+        seq = A.estimate_transform_cv_sequence(s, z["est_dst"], False)          # the restated RANSAC + LM sequence as well
+        assert np.abs(seq - m).max() <= 1e-6 * max(1.0, np.abs(m).max())
+    assert worst_abs < 1e-9 and worst_rel < 1e-13, (worst_abs, worst_rel)

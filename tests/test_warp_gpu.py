@@ -75,3 +75,14 @@ def test_degenerate_face_is_flagged(device):
     crops, ok, _ = align.crop_align(img, torch.zeros(2, dtype=torch.int32), lm, A.landmarks_target((16, 16), 0.65),
                                     (16, 16))
     assert ok.cpu().tolist() == [0, 1]
+
+
+def test_estimate_transform_matches_scikit_image_umeyama(device):
+    """The kernel's closed form against scikit-image's Umeyama estimate (fixture: tests/golden/make_golden_skimage.py)."""
+    import os
+    from face_crop_plus_amd import align
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage_similarity.npz"))
+    mat, ok = align.estimate_transform(torch.from_numpy(z["est_src"]).to(device), torch.from_numpy(z["est_dst"]).to(device), False)
+    mat, ok = mat.cpu().numpy().reshape(-1, 2, 3), ok.cpu().numpy()
+    assert ok.all()
+    assert np.abs(mat - z["est_mat"]).max() < 1e-9
