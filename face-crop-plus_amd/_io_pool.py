@@ -52,22 +52,28 @@ def _serve(conn, ring, ring_bytes: int, ctl, slot: int):
         try:
             with warnings.catch_warnings(record=True) as caught:
                 warnings.simplefilter("always")
-                if kind == "read":
-                    img = read_image(msg[1])
-                    notes = [str(w.message) for w in caught]
-                    if img is None:
-                        conn.send(("none", notes))
-                        continue
-                    need = img.nbytes
-                    pos = produced % ring_bytes if ring_bytes else 0
-                    skip = ring_bytes - pos if ring_bytes and pos + need > ring_bytes else 0
-                    if ring_bytes and need <= ring_bytes and produced + skip + need - int(consumed[slot]) <= ring_bytes:
-                        off = (pos + skip) % ring_bytes
-                        np.frombuffer(ring, dtype=np.uint8, count=need, offset=off)[:] = img.reshape(-1)
-                        produced += skip + need
-                        conn.send(("ring", off, img.shape, skip + need, notes))
-                    else:                                   # no room right now: through the socket, never wait
-                        conn.send(("pipe", img.shape, notes))
+                if kind == "read":                          # one request for a list of files, ONE reply for all of them
+                    replies, through_socket = [], []
+                    for path in msg[1]:
+                        seen = len(caught)
+                        img = read_image(path)
+                        notes = [str(w.message) for w in caught[seen:]]
+                        if img is None:
+                            replies.append(("none", notes))
+                            continue
+                        need = img.nbytes
+                        pos = produced % ring_bytes if ring_bytes else 0
+                        skip = ring_bytes - pos if ring_bytes and pos + need > ring_bytes else 0
+                        if ring_bytes and need <= ring_bytes and produced + skip + need - int(consumed[slot]) <= ring_bytes:
+                            off = (pos + skip) % ring_bytes
+                            np.frombuffer(ring, dtype=np.uint8, count=need, offset=off)[:] = img.reshape(-1)
+                            produced += skip + need
+                            replies.append(("ring", off, img.shape, skip + need, notes))
+                        else:                               # no room right now: through the socket, never wait
+                            replies.append(("pipe", img.shape, notes))
+                            through_socket.append(img)
+                    conn.send(("read", replies))
+                    for img in through_socket:
                         conn.send_bytes(memoryview(np.ascontiguousarray(img)).cast("B"))
                 elif kind == "write":
                     _, path, shape = msg
@@ -135,24 +141,34 @@ class _Worker:
             raise RuntimeError(f"I/O worker: {rep[1]}")
         return rep
 
+    def read_many(self, paths):
+        """-> [(RGB uint8 HWC array or None, release token or None)] in the order of ``paths``: one request, one reply.
+        Warnings of the decoder are re-issued here."""
+        self.conn.send(("read", list(paths)))
+        out = []
+        for rep in self._reply()[1]:
+            for note in rep[-1]:
+                warnings.warn(note)
+            if rep[0] == "none":
+                out.append((None, None))
+            elif rep[0] == "pipe":
+                out.append((rep[1], "pipe"))                 # payload follows the reply, in order
+            else:
+                _, off, shape, nbytes, _ = rep
+                arr = np.frombuffer(self.ring, dtype=np.uint8, count=int(np.prod(shape)), offset=off).reshape(shape)
+                with self.lock:
+                    self.seq += 1
+                    self.regions[self.seq] = [nbytes, False]
+                    out.append((arr, (self, self.seq)))
+        for k, (shape, tok) in enumerate(out):
+            if tok == "pipe":
+                buf = bytearray(int(np.prod(shape)))
+                self.conn.recv_bytes_into(buf)
+                out[k] = (np.frombuffer(buf, dtype=np.uint8).reshape(shape), None)
+        return out
+
     def read(self, path):
-        """-> (RGB uint8 HWC array or None, release token or None).  Warnings of the decoder are re-issued here."""
-        self.conn.send(("read", path))
-        rep = self._reply()
-        for note in rep[-1]:
-            warnings.warn(note)
-        if rep[0] == "none":
-            return None, None
-        if rep[0] == "pipe":
-            buf = bytearray(int(np.prod(rep[1])))
-            self.conn.recv_bytes_into(buf)
-            return np.frombuffer(buf, dtype=np.uint8).reshape(rep[1]), None
-        _, off, shape, nbytes, _ = rep
-        arr = np.frombuffer(self.ring, dtype=np.uint8, count=int(np.prod(shape)), offset=off).reshape(shape)
-        with self.lock:
-            self.seq += 1
-            self.regions[self.seq] = [nbytes, False]
-            return arr, (self, self.seq)
+        return self.read_many([path])[0]
 
     @staticmethod
     def is_pinned(token) -> bool:
@@ -249,6 +265,9 @@ class IOProcesses:
 
     def read(self, path):
         return self._mine("r", self._free_r).read(path)
+
+    def read_many(self, paths):
+        return self._mine("r", self._free_r).read_many(paths)
 
     def write(self, path, pixels):
         return self._mine("w", self._free_w).write(path, pixels)

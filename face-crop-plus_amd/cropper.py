@@ -357,20 +357,30 @@ class Cropper:
             procs.begin()
             io = ThreadPoolExecutor(max_workers=procs.readers, thread_name_prefix="fcp-read")
             wio = ThreadPoolExecutor(max_workers=procs.writers, thread_name_prefix="fcp-write")
-            read_one = procs.read
+            read_one = None
         else:
             io = wio = ThreadPoolExecutor(max_workers=self.io_threads, thread_name_prefix="fcp-io")
             read_one = lambda path: (read_image(path), None)
         self._io_procs_active = procs
         writes = []
         self._io = (wio, writes, BoundedSemaphore(self.MAX_PENDING_WRITES))
-        # every file is its own decode task (a batch decoded by one thread would cap the pipeline at `depth` decoders)
+        # Threads: every file is its own decode task (a batch decoded by one thread would cap the pipeline at `depth`
+        # decoders).  Worker processes: a batch is dealt round-robin into one request per decoder — the parent's relay
+        # threads wake up once per request, not once per image (their wake-ups contend for the interpreter lock).
         def submit_read(i):
-            return [io.submit(read_one, os.path.join(input_dir, f)) for f in file_batches[i]]
+            paths = [os.path.join(input_dir, f) for f in file_batches[i]]
+            if procs is None:
+                return [io.submit(read_one, p_) for p_ in paths]
+            k = min(procs.readers, len(paths))
+            return [(paths[j::k], io.submit(procs.read_many, paths[j::k])) for j in range(k)]
 
         def collect_read(i, futs):
             """-> images, surviving names, release tokens of the shared-memory regions the images live in."""
-            decoded = [f.result() for f in futs]
+            if procs is None:
+                decoded = [f.result() for f in futs]
+            else:                                    # undo the round-robin deal: image m of the batch is item m // k of chunk m % k
+                chunks = [f.result() for _, f in futs]
+                decoded = [chunks[m % len(chunks)][m // len(chunks)] for m in range(len(file_batches[i]))]
             ok = [k for k, (im, _) in enumerate(decoded) if im is not None]
             return [decoded[k][0] for k in ok], np.array(file_batches[i])[ok], [decoded[k][1] for k in ok]
 

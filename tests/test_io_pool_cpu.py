@@ -89,3 +89,21 @@ def test_workers_exit_with_the_pool(tmp_path):
     for pid in pids:
         with pytest.raises(OSError):
             os.kill(pid, 0)                                                     # gone (and reaped)
+
+
+def test_read_many_one_reply_keeps_order_with_unreadable_and_oversize_files(pool, tmp_path):
+    from PIL import Image
+    big = _img(700, 700, 1)                                                     # 1.47 MB > the 1 MiB ring: through the socket
+    imgs = {"a.png": _img(100, 120, 2), "big.png": big, "b.png": _img(90, 80, 3), "c.png": _img(64, 64, 4)}
+    for name, im in imgs.items():
+        Image.fromarray(im).save(tmp_path / name)
+    (tmp_path / "bad.png").write_bytes(b"nope")
+    order = ["a.png", "big.png", "bad.png", "b.png", "c.png"]
+    with pytest.warns(UserWarning, match="Could not read"):
+        got = pool.read_many([str(tmp_path / n) for n in order])
+    assert [g[0] is None for g in got] == [False, False, True, False, False]
+    for name, (arr, tok) in zip(order, got):
+        if name != "bad.png":
+            assert np.array_equal(arr, imgs[name]), name
+    assert [tok is not None for _, tok in got] == [True, False, False, True, True]
+    pool.release([tok for _, tok in got])
