@@ -457,10 +457,10 @@ class Cropper:
         want = self.io_processes
         if want is None:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
-            # measured on a 2 x 64-core EPYC 9575F box (1024 JPEGs of 640^2, two GPU workers): (4, 2) 2390, (6, 2) 2420,
-            # (8, 3) 2170, (12, 3) 2020, (16, 6) 1880, (24, 8) 1750 images/s — one worker decodes ~600 images/s, and every
-            # further relay thread in the parent only adds contention for the interpreter lock
-            want = (max(2, min(6, cores // 4)), max(1, min(2, cores // 8)))
+            # measured on a 2 x 64-core EPYC 9575F box (2048 JPEGs of 640^2, one decode request per decoder and batch;
+            # 2 / 3 GPU workers): (8, 3) 2320 / 2650, (12, 3) 2360 / 2750, (12, 4) 2300 / 2540, (16, 4) 2270 / 2600,
+            # (24, 4) 2110 / 2650 images/s — flat beyond a dozen decoders (one decodes ~600 images/s)
+            want = (max(2, min(12, cores // 3)), max(1, min(3, cores // 8)))
         if min(want) <= 0:
             return None
         have = self._io_procs
