@@ -93,9 +93,16 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT>
+// PATCH (conv2 forms, 128-pixel tiles): the tile is an 8 x 16 PATCH of one image instead of 128 consecutive pixels, and
+// phase 1 stages the patch's (8 + 2) x (16 + 2) halo ONCE per 32-channel slice; the nine taps read it at shifted rows (the
+// scheme of conv3x3_halo_f16x3).  The linear form fetches a 128-byte operand row per pixel, tap and slice: 288 of the ~720
+// one-KiB vector-memory instructions a tile issues — and the chain kernels are bound by exactly that path
+// (profiles/r04_probes.md section 1: same cycles with and without their MFMAs).  The halo form issues 46.  Same K order (channel
+// slice outer, taps inner), same terms: bit-identical.
+template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false>
 __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT / 128) bneck_chain_c64(const ChainK p) {
   static_assert(!HAS_C2 || CW == C, "phase 1 is written for 64-channel bottlenecks");
+  static_assert(!PATCH || (HAS_C2 && BMT == 128), "the patch form is the 128-pixel conv2 form");
   static_assert(BMT == 128 || BMT == 256, "tile height");
   constexpr int NTHR = 2 * BMT;                     // threads: one wave per 32 rows
   constexpr int NW = NTHR / 64;                     // waves
@@ -155,9 +162,156 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     offL[s] = ((4 + 2 * s + half) ^ rsw) << 4;
   }
   const int hw = p.h * p.w;
+  // tile row -> pixel index in (n, h, w) order, or -1 for a row that has no pixel (past the end / outside the image)
+  int pn = 0, py0 = 0, px0 = 0;                                  // PATCH: image and top-left pixel of the 8 x 16 patch
+  if constexpr (PATCH) {
+    const int txn = (p.w + 15) >> 4, tyn = (p.h + 7) >> 3;
+    const int r = tile_m / txn;
+    px0 = (tile_m - r * txn) * 16;
+    pn = r / tyn;
+    py0 = (r - pn * tyn) * 8;
+  }
+  auto pix = [&](int row) -> long {
+    if constexpr (PATCH) {
+      const int y = py0 + (row >> 4), x = px0 + (row & 15);
+      return (y < p.h && x < p.w) ? ((long)pn * p.h + y) * p.w + x : -1L;
+    } else {
+      const long m = (long)tile_m * BMT + row;
+      return m < p.M ? m : -1L;
+    }
+  };
+
+  // ---- conv2 epilogue (both phase-1 forms): fp32 tile [BMT][64] over the dead phase-1 buffers -> relu(acc * ws2 + b2) -> T2
+  auto conv2_epilogue = [&](const f32x16 (&acc1)[2], int wm, int wn) {
+    float* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = wm * 64 + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        Cs[row * C + wn * 32 + l31] = acc1[i][rr];
+      }
+    __syncthreads();
+    {
+      const int ccol = (tid & 7) * 8;
+      float ws8[8], b8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ws8[e] = p.ws2[ccol + e];
+        b8[e] = p.b2[ccol + e];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = (tid >> 3) + LR * g;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * C + ccol);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * C + ccol + 4);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = v[e] * ws8[e] + b8[e];
+          x = x >= 0.f ? x : x * 0.f;
+          v[e] = x * 1.f;
+        }
+        u32x4_t hi, lo;
+        split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+        const int q = (ccol & 31) >> 3, sw = swz(row);
+        char* trow = lds + T2_OFF + (ccol >> 5) * (BMT * ROWB) + row * ROWB;
+        *reinterpret_cast<u32x4_t*>(trow + ((q ^ sw) << 4)) = hi;
+        *reinterpret_cast<u32x4_t*>(trow + (((4 + q) ^ sw) << 4)) = lo;
+      }
+    }
+    __syncthreads();                                             // T2 complete; the fp32 tile is dead
+  };
 
   // =========================================================================================== phase 1: 3x3 conv
-  if constexpr (HAS_C2) {
+  if constexpr (HAS_C2 && PATCH) {
+    constexpr int HROWS = 192;                                   // 10 x 18 = 180 halo rows, padded to whole DMA passes
+    constexpr int ASL = HROWS * ROWB;                            // one channel slice of the halo patch: 24 KiB
+    constexpr int BST_OFF = 2 * ASL, BSTG = C * ROWB;            // two 8 KiB filter stages behind the two slices
+    static_assert(BST_OFF + 2 * BSTG <= T2_OFF + BMT * C * 4, "halo patch + filter stages must fit region 0 + T2");
+    f32x16 acc1[2];
+    const int wm = wave / 2, wn = wave % 2;                      // 2 x 2 waves of 64 x 32, as in the linear form
+    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t1), 0, p.t1_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2), 0, p.w2_bytes, 0x00020000);
+    // ---- the halo patch, both channel slices: 6 passes of 32 rows each (rows >= 180 and pixels outside the image: zero fill)
+#pragma unroll
+    for (int i = 0; i < HROWS / LR; ++i) {
+      const int r = lrow + LR * i;
+      const int hy = r / 18, hx = r - hy * 18;
+      const int y = py0 - 1 + hy, x = px0 - 1 + hx;
+      const bool ok = r < 180 && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
+      const unsigned src = ok ? ((unsigned)((pn * p.h + y) * p.w + x) * (unsigned)p.t1_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
+#pragma unroll
+      for (int cs = 0; cs < 2; ++cs)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(lds + cs * ASL + (wave_u * 8 + LR * i) * ROWB), 16,
+                                                 (int)(src == 0xFFFFFFFFu ? 0xFFFFFFFFu : src + (unsigned)(cs * 32 * 4)), 0, 0, 0);
+    }
+    constexpr int B_LD = C / LR;
+    unsigned woff[B_LD];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((lrow + LR * i) * (9 * C) + csrc * 4) * 4);
+    auto dma_b = [&](int kt, int stage) {
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + BST_OFF + stage * BSTG + (wave_u * 8 + LR * i) * ROWB), 16,
+                                                 (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
+    };
+    dma_b(0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc1[i][e] = 0.f;
+    // halo row of the lane's pixel in the wave's two 32-row tiles: pixel p = wm * 64 + 32 i + l31 -> (p >> 4, p & 15)
+    int hr0[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) hr0[i] = (wm * 4 + i * 2 + (l31 >> 4)) * 18 + (l31 & 15);
+    const char* Bw = lds + BST_OFF + (wn * 32 + l31) * ROWB;
+    for (int cs = 0; cs < 2; ++cs) {
+      static_for<0, 9>([&](auto tc) {
+        constexpr int tap = decltype(tc)::value;
+        const int kt = cs * 9 + tap;
+        // filter slice kt has landed (with the halo patch, at kt = 0) and every wave has read slice kt - 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* Bb = Bw + (kt & 1) * BSTG;
+        f16x8 ah[2][2], al[2][2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int hr = hr0[i] + (tap / 3) * 18 + tap % 3;
+          const int sw = swz(hr);
+          const char* Ab = lds + cs * ASL + hr * ROWB;
+#pragma unroll
+          for (int sq = 0; sq < 2; ++sq) {
+            ah[sq][i] = *reinterpret_cast<const f16x8*>(Ab + (((2 * sq + half) ^ sw) << 4));
+            al[sq][i] = *reinterpret_cast<const f16x8*>(Ab + (((4 + 2 * sq + half) ^ sw) << 4));
+          }
+        }
+#pragma unroll
+        for (int sq = 0; sq < 2; ++sq) {
+          bh[sq] = *reinterpret_cast<const f16x8*>(Bb + offH[sq]);
+          bl[sq] = *reinterpret_cast<const f16x8*>(Bb + offL[sq]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < 18) dma_b(kt + 1, (kt + 1) & 1);            // into the stage slice kt - 1 has left
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sq = 0; sq < 2; ++sq)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sq][i], bh[sq], acc1[i], 0, 0, 0);
+            acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sq][i], bl[sq], acc1[i], 0, 0, 0);
+            acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sq][i], bh[sq], acc1[i], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // every wave has consumed the last slice: patch and stages are dead
+    __builtin_amdgcn_sched_barrier(0);
+    conv2_epilogue(acc1, wm, wn);
+  } else if constexpr (HAS_C2) {
     f32x16 acc1[2];
     constexpr int A_LD = BMT / LR, B_LD = C / LR;
     const int wm = wave / 2, wn = wave % 2;                      // (NW / 2) x 2 waves of 64 x 32
@@ -282,45 +436,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     __builtin_amdgcn_s_barrier();                                  // every wave has consumed the last slice: the stages are dead
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- conv2 epilogue: fp32 tile [BMT][64] over the dead stages -> relu(acc * ws2 + b2) -> T2 operand image
-    float* Cs = smem;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int row = wm * 64 + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-        Cs[row * C + wn * 32 + l31] = acc1[i][rr];
-      }
-    __syncthreads();
-    {
-      const int ccol = (tid & 7) * 8;
-      float ws8[8], b8[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        ws8[e] = p.ws2[ccol + e];
-        b8[e] = p.b2[ccol + e];
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = (tid >> 3) + LR * g;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * C + ccol);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * C + ccol + 4);
-        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = v[e] * ws8[e] + b8[e];
-          x = x >= 0.f ? x : x * 0.f;
-          v[e] = x * 1.f;
-        }
-        u32x4_t hi, lo;
-        split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
-        const int q = (ccol & 31) >> 3, sw = swz(row);
-        char* trow = lds + T2_OFF + (ccol >> 5) * (BMT * ROWB) + row * ROWB;
-        *reinterpret_cast<u32x4_t*>(trow + ((q ^ sw) << 4)) = hi;
-        *reinterpret_cast<u32x4_t*>(trow + (((4 + q) ^ sw) << 4)) = lo;
-      }
-    }
-    __syncthreads();                                             // T2 complete; the fp32 tile is dead
+    conv2_epilogue(acc1, wm, wn);
   } else {
     // ---- no conv2: the operand tile is the input itself (CS slices of 128 pixels x 128 B), by LDS-DMA
     __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t1), 0, p.t1_bytes, 0x00020000);
@@ -394,14 +510,13 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   // MFMAs beside another's epilogue); what the waves share are the filter buffers: ONE barrier per chunk.
   const int eq = lane & 3;
   const int erow0 = wave * 32 + (lane >> 2);
-  const long em0 = (long)tile_m * BMT + erow0;
   long rm[2];                                                    // residual pixel of the two items (clamped)
   unsigned so[2];                                                // byte offset of the two items in `out`, 0xFFFFFFFF past the end
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const long m = em0 + 16 * it;
-    rm[it] = m < p.M ? m : (long)p.M - 1;
-    so[it] = (m < p.M) ? (unsigned)(m * p.out_ld * 4 + eq * 16) : 0xFFFFFFFFu;
+    const long m = pix(erow0 + 16 * it);
+    rm[it] = m >= 0 ? m : (long)p.M - 1;
+    so[it] = m >= 0 ? (unsigned)(m * p.out_ld * 4 + eq * 16) : 0xFFFFFFFFu;
   }
   __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
@@ -727,7 +842,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int row = (tid >> 3) + LR * g;
-      const long m = (long)tile_m * BMT + row;
+      const long m = pix(row);
       const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ccol);
       const f32x4 b = *reinterpret_cast<const f32x4*>(Cs + row * 64 + ccol + 4);
       float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -737,7 +852,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
         x = x >= 0.f ? x : x * 0.f;
         v[e] = x * 1.f;
       }
-      if (m >= p.M) continue;
+      if (m < 0) continue;
       u32x4_t hi, lo;
       split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
       char* ob = reinterpret_cast<char*>(p.t1n) + m * p.t1n_ld * 4 + split_chan_off(co);
@@ -753,11 +868,12 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   }
 }
 
-template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT>
+template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false>
 int launch(const ChainK& k, hipStream_t s) {
   constexpr int LDS = lds_bytes(BMT, CW, CN, HAS_C2);
-  FCP_LDS_OPT_IN((&bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT>), LDS);
-  hipLaunchKernelGGL((bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT>), dim3(fcp_cdiv(k.M, BMT)), dim3(2 * BMT), LDS, s, k);
+  FCP_LDS_OPT_IN((&bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH>), LDS);
+  const int tiles = PATCH ? k.n * ((k.h + 7) >> 3) * ((k.w + 15) >> 4) : fcp_cdiv(k.M, BMT);
+  hipLaunchKernelGGL((bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH>), dim3(tiles), dim3(2 * BMT), LDS, s, k);
   FCP_LAUNCH_OK();
   return 0;
 }
@@ -808,9 +924,12 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   // the registers (same bits; measured 0-6 % slower: what halving the filter traffic gains, one barrier domain of eight
   // waves loses — profiles/r03_probes.md)
   const bool big = d->tile_m == 256;
+  // d->tile_m = 16: the conv2 forms on 8 x 16 patches with a staged halo (PATCH; same bits)
+  const bool patch = d->tile_m == 16;
+  FCP_REQUIRE(!patch || has_c2, "chain: tile_m = 16 (8 x 16 patches) exists for the conv2 forms only");
   switch (variant) {
-    case 1: return big ? launch<64, 64, 256, true, true, 256>(k, s) : launch<64, 64, 256, true, true, 128>(k, s);
-    case 2: return big ? launch<128, 64, 256, true, true, 256>(k, s) : launch<128, 64, 256, true, true, 128>(k, s);
+    case 1: return patch ? launch<64, 64, 256, true, true, 128, true>(k, s) : big ? launch<64, 64, 256, true, true, 256>(k, s) : launch<64, 64, 256, true, true, 128>(k, s);
+    case 2: return patch ? launch<128, 64, 256, true, true, 128, true>(k, s) : big ? launch<128, 64, 256, true, true, 256>(k, s) : launch<128, 64, 256, true, true, 128>(k, s);
     case 3: return big ? launch<128, 128, 512, false, true, 256>(k, s) : launch<128, 128, 512, false, true, 128>(k, s);
     case 5: return launch<256, 256, 1024, false, true, 128>(k, s);
     case 6: return launch<256, 128, 512, false, true, 128>(k, s);     // CN = 256: 128 accumulator registers, one wave per SIMD only

@@ -598,6 +598,9 @@ def chain_supported(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, r
 
 HALO_WIDE = os.environ.get("FCP_HALO_WIDE", "1") != "0"       # A/B switch: offer the wide halo-tile kernel to the tile tuner
 CHAIN_TILE_M = int(os.environ.get("FCP_CHAIN_TILE_M", "0"))   # 0 / 128: 4-wave tiles of 128 pixels; 256: 8-wave tiles where they fit
+# conv2 forms (layer 1): 8 x 16 pixel patches whose halo is staged once per channel slice (tile_m = 16 in the descriptor)
+# instead of 128 consecutive pixels fetched once per tap; same bits.  FCP_CHAIN_PATCH=0 = the linear tiles.
+CHAIN_PATCH = os.environ.get("FCP_CHAIN_PATCH", "1") != "0"
 
 
 def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, t1: Act, res: Act | None,
@@ -616,12 +619,13 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     opt = lambda pc, f: None if pc is None else getattr(pc, f)
+    if tile_m is None:
+        tile_m = 16 if (pc2 is not None and CHAIN_PATCH and CHAIN_TILE_M == 0) else CHAIN_TILE_M
     if T.ENABLED and out is None and t1n is None:
         # FCP_BOUNDARY=torch: the registered custom op allocates and returns both tensors
         o, t = T.load().bottleneck_chain(t1.buf, t1.c0, None if res is None else res.buf, 0 if res is None else res.c0,
                                          opt(pc2, "w"), opt(pc2, "wscale"), opt(pc2, "bias"), pc3.w, pc3.wscale, pc3.bias,
-                                         pc1n.w, pc1n.wscale, pc1n.bias, pc3.cin, pc3.cout, pc1n.cout,
-                                         CHAIN_TILE_M if tile_m is None else tile_m)
+                                         pc1n.w, pc1n.wscale, pc1n.bias, pc3.cin, pc3.cout, pc1n.cout, tile_m)
         out, t1n = Act(o, fmt=1), Act(t, fmt=1)
     else:
         if out is None:
@@ -637,7 +641,7 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
         d.w1n, d.ws1n, d.b1n = N.ptr(pc1n.w), N.ptr(pc1n.wscale), N.ptr(pc1n.bias)
         d.n, d.h, d.w, d.c, d.cn, d.nout = t1.n, t1.h, t1.w, pc3.cin, pc1n.cout, pc3.cout
         d.t1_ld, d.res_ld, d.out_ld, d.t1n_ld = t1.ld, (res.ld if res is not None else 0), out.ld, t1n.ld
-        d.tile_m = CHAIN_TILE_M if tile_m is None else tile_m
+        d.tile_m = tile_m
         N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
     if timing is not None:
         e1.record()

@@ -158,8 +158,10 @@ typedef struct fcp_chain_desc {
   int32_t n, h, w, c, cn;
   int32_t t1_ld, res_ld, out_ld, t1n_ld;
   int32_t nout;       /* conv3's filters: 4c with conv2; see the pair forms below */
-  int32_t tile_m;     /* pixels per workgroup tile: 0 / 128 = 4-wave tiles (two workgroups per CU), 256 = 8-wave tiles
-                       * where the operand tile fits LDS (the other forms keep 128).  Same bits either way. */
+  int32_t tile_m;     /* pixels per workgroup tile: 0 / 128 = 4-wave tiles of 128 consecutive pixels (two workgroups per
+                       * CU), 256 = 8-wave tiles where the operand tile fits LDS (the other forms keep 128), 16 = (conv2
+                       * forms only) 4-wave tiles that are 8 x 16 pixel patches of one image, conv2's operand staged
+                       * once per channel slice as the patch's halo.  Same bits whichever is chosen. */
 } fcp_chain_desc;
 
 int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* desc, fcp_stream_t stream);

@@ -18,7 +18,8 @@ def _ref_bn(x, bn):
     return F.batch_norm(x, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, 1e-5)
 
 
-@pytest.mark.parametrize("n,h,w,cn", [(2, 37, 45, 64), (1, 16, 16, 128), (3, 64, 50, 128), (1, 5, 3, 64), (4, 160, 160, 64)])
+@pytest.mark.parametrize("n,h,w,cn", [(2, 37, 45, 64), (1, 16, 16, 128), (3, 64, 50, 128), (1, 5, 3, 64), (4, 160, 160, 64), (2, 8, 16, 64),
+                                      (1, 9, 17, 128), (3, 23, 31, 64)])
 def test_chain_equals_three_convs(n, h, w, cn, device):
     from face_crop_plus_amd import engine as E
     g = torch.Generator().manual_seed(n * 1000 + h)
@@ -40,10 +41,13 @@ def test_chain_equals_three_convs(n, h, w, cn, device):
     o2 = E.conv(pc2, t1a, act_slope=0.0, out_fmt=1)
     o3 = E.conv(pc3, o2, act_slope=0.0, res1=xa, res1_pre=True, out_fmt=1)
     o1 = E.conv(pc1, o3, act_slope=0.0, out_fmt=1)
-    out, t1n = E.bottleneck_chain(pc2, pc3, pc1, t1a, xa)
+    out, t1n = E.bottleneck_chain(pc2, pc3, pc1, t1a, xa)                 # default form: 8 x 16 patches, staged halo
     torch.cuda.synchronize()
     assert torch.equal(out.buf, o3.buf), "fused conv3 output differs from the stand-alone kernels"
     assert torch.equal(t1n.buf, o1.buf), "fused next-conv1 output differs from the stand-alone kernels"
+    for tm in (128, 16, 256):                                              # linear 4-wave tiles, patches, 8-wave tiles: same bits
+        o_t, t_t = E.bottleneck_chain(pc2, pc3, pc1, t1a, xa, tile_m=tm)
+        assert torch.equal(o_t.buf, o3.buf) and torch.equal(t_t.buf, o1.buf), f"tile_m={tm}"
     # and against torch fp32
     r2 = F.relu(_ref_bn(F.conv2d(t1, w2, None, 1, 1), bn2))
     r3 = F.relu(_ref_bn(F.conv2d(r2, w3), bn3) + x)

@@ -32,6 +32,9 @@ for cn in (64, 128):
     out, t1n = E.Act.empty(b, h, h, 256, dev, 1), E.Act.empty(b, h, h, cn, dev, 1)
     o2 = E.Act.empty(b, h, h, 64, dev, 1)
     tc = timeit(lambda: E.bottleneck_chain(pc2, pc3, pc1, t1, x, out, t1n))
+    tl = timeit(lambda: E.bottleneck_chain(pc2, pc3, pc1, t1, x, out, t1n, tile_m=128))
+    tp = timeit(lambda: E.bottleneck_chain(pc2, pc3, pc1, t1, x, out, t1n, tile_m=16))
+    print(f"cn={cn}: linear 128-pixel tiles {tl:7.1f} us, 8 x 16 patches {tp:7.1f} us", flush=True)
     t2 = timeit(lambda: E.conv(pc2, t1, o2, act_slope=0.0))
     t3 = timeit(lambda: E.conv(pc3, o2, out, act_slope=0.0, res1=x))
     t1_ = timeit(lambda: E.conv(pc1, out, t1n, act_slope=0.0))
