@@ -217,3 +217,33 @@ def test_similarity_matches_scikit_image_umeyama():
         seq = A.estimate_transform_cv_sequence(s, z["est_dst"], False)          # the restated RANSAC + LM sequence as well
         assert np.abs(seq - m).max() <= 1e-6 * max(1.0, np.abs(m).max())
     assert worst_abs < 1e-9 and worst_rel < 1e-13, (worst_abs, worst_rel)
+
+
+def _skimage_warp_cases():
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage_warp.npz"))
+    for k in range(int(z["cases"])):
+        img, (ow, oh) = z[f"img{k}"], z[f"dsize{k}"]
+        h, w = img.shape[:2]
+        for M, x8 in zip(z[f"mat{k}"], z[f"x8_{k}"]):
+            inv = np.linalg.inv(np.vstack([M, [0, 0, 1]]))
+            xs, ys = np.meshgrid(np.arange(ow), np.arange(oh))
+            sx, sy = inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2], inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]
+            interior = (sx >= 0.5) & (sx <= w - 1.5) & (sy >= 0.5) & (sy <= h - 1.5)       # footprint strictly inside the image
+            yield img, M, (int(ow), int(oh)), x8.astype(np.float64) / 8, interior
+
+
+def test_warp_geometry_matches_scikit_image():
+    """Third-party check of row a14's geometry: scikit-image 0.18.3 `transform.warp(order=1)` (float64 bilinear, same
+    conventions as cv2.warpAffine) on smooth images; fixture from tests/golden/make_golden_skimage_warp.py.  The fixed-point
+    restatement must stay within one grey level wherever the 2 x 2 footprint lies inside the image (the two libraries
+    treat the outermost half pixel of a constant border differently), with a rounding-sized mean."""
+    n = 0
+    for img, M, dsize, ref, interior in _skimage_warp_cases():
+        got = A.warp_affine(img, M, dsize, 0).astype(np.float64)
+        d = np.abs(got - ref)[interior]
+        assert interior.mean() > 0.3 and d.max() <= 1.0 and d.mean() < 0.3, (d.max(), d.mean())
+        outside = np.abs(got - ref)[~interior]
+        assert outside.size == 0 or np.median(outside) <= 1.0            # far outside both give the border constant
+        n += 1
+    assert n == 9

@@ -86,3 +86,24 @@ def test_estimate_transform_matches_scikit_image_umeyama(device):
     mat, ok = mat.cpu().numpy().reshape(-1, 2, 3), ok.cpu().numpy()
     assert ok.all()
     assert np.abs(mat - z["est_mat"]).max() < 1e-9
+
+
+def test_warp_kernel_geometry_matches_scikit_image(device):
+    """The kernel on the scikit-image geometry fixture (tests/test_align_oracle.py::test_warp_geometry_matches_scikit_image):
+    byte-equal to the oracle there, hence within one grey level of an independent bilinear resampler in the interior."""
+    import importlib.util, os
+    from face_crop_plus_amd import _native as N
+    spec = importlib.util.spec_from_file_location("_align_oracle_tests", os.path.join(os.path.dirname(__file__), "test_align_oracle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    _skimage_warp_cases = mod._skimage_warp_cases
+    for img, M, (ow, oh), ref, interior in _skimage_warp_cases():
+        images = torch.from_numpy(img[None].copy()).to(device)
+        mat = torch.from_numpy(M.reshape(1, 6).copy()).to(device)
+        idx = torch.zeros(1, dtype=torch.int32, device=device)
+        out = torch.empty((1, oh, ow, 3), dtype=torch.uint8, device=device)
+        N.check(N.lib().fcp_warp_affine_u8(N.ptr(images), 1, img.shape[0], img.shape[1], N.ptr(idx), N.ptr(mat), None, None, 1, oh, ow, 0,
+                                           N.ptr(out), N.stream_ptr()), "fcp_warp_affine_u8")
+        got = out.cpu().numpy()[0]
+        assert np.array_equal(got, A.warp_affine(img, M, (ow, oh), 0))
+        assert np.abs(got.astype(np.float64) - ref)[interior].max() <= 1.0
