@@ -121,3 +121,18 @@ def test_build_batch_direct_upload_from_registered_rings(tmp_path, device):
         pool.release([t for _, t in got])
     finally:
         pool.close()
+
+
+def test_area_integral_ratios_match_scikit_image_block_means(device):
+    """The batch-builder kernel on the scikit-image block-mean fixture (tests/test_batch_oracle.py): INTER_AREA at integral
+    ratios is the rounded block mean; the kernel equals the oracle byte for byte there as everywhere."""
+    import os
+    from face_crop_plus_amd.batch import build_batch
+    from oracle import batch_ref as B
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage_area.npz"))
+    for k in range(int(z["cases"])):
+        img, f = z[f"img{k}"], int(z[f"factor{k}"])
+        h, w = img.shape[0] // f, img.shape[1] // f
+        got = build_batch([img], (w, h), "constant", device)[0].cpu().numpy()[0]      # exact fit: no padding
+        assert np.array_equal(got, B.resize_area_u8(img, w, h))
+        assert np.abs(got.astype(np.float64) - z[f"mean_x64_{k}"].astype(np.float64) / 64).max() <= 0.5 + 1 / 64

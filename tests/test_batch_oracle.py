@@ -138,3 +138,19 @@ def test_as_batch_shapes_and_unscales():
     assert np.allclose(unscales, [0.8, 64 / 90, 1.0, 64 / 30])
     assert np.array_equal(batch[2], imgs[2])                        # same size: untouched
     assert batch[0, :12].sum() == 0 and batch[0, 52:].sum() == 0 and batch[1, :, :18].sum() == 0
+
+
+def test_area_integral_ratios_match_scikit_image_block_means():
+    """Third-party check of row f1 at integral ratios: scikit-image 0.18.3 `downscale_local_mean` (fixture from
+    tests/golden/make_golden_skimage_area.py; OpenCV is not in the image).  INTER_AREA is the rounded block mean there:
+    (s + 2) >> 2 for 2 x 2 (ties up), cvRound(sum * (1.f / area)) otherwise (ties to even, float32 product)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage_area.npz"))
+    for k in range(int(z["cases"])):
+        img, f = z[f"img{k}"], int(z[f"factor{k}"])
+        mean = z[f"mean_x64_{k}"].astype(np.float64) / 64
+        got = B.resize_area_u8(img, img.shape[1] // f, img.shape[0] // f).astype(np.float64)
+        assert got.shape == mean.shape
+        assert np.abs(got - mean).max() <= 0.5 + 1 / 64, (f, np.abs(got - mean).max())      # a rounding of the same mean
+        off_tie = np.abs(mean - np.floor(mean) - 0.5) > 1 / 32
+        assert np.array_equal(got[off_tie], np.rint(mean)[off_tie])                              # identical away from exact ties
