@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_f32p = C.c_void_p
 _lib = None
@@ -39,13 +39,14 @@ class ConvDesc(C.Structure):
 
 CONV_FLAT_ADDR = 1      # fcp_conv_desc.flags: FCP_CONV_FLAT_ADDR
 CONV_BALANCE_TAIL = 2   # fcp_conv_desc.flags: FCP_CONV_BALANCE_TAIL
+CHAIN_OUT_EVEN_ONLY = 1  # fcp_chain_desc.flags: FCP_CHAIN_OUT_EVEN_ONLY
 
 
 class ChainDesc(C.Structure):
     """Mirror of ``fcp_chain_desc``."""
     _fields_ = [(k, C.c_void_p) for k in ("t1", "w2", "ws2", "b2", "w3", "ws3", "b3", "res", "out", "w1n", "ws1n",
                                           "b1n", "t1n")] + \
-               [(k, C.c_int32) for k in ("n", "h", "w", "c", "cn", "t1_ld", "res_ld", "out_ld", "t1n_ld", "nout", "tile_m")]
+               [(k, C.c_int32) for k in ("n", "h", "w", "c", "cn", "t1_ld", "res_ld", "out_ld", "t1n_ld", "nout", "tile_m", "flags")]
 
 
 # name -> argtypes; every function returns int (0 = ok)

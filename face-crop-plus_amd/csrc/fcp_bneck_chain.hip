@@ -55,6 +55,7 @@ struct ChainK {
   float* t1n;       int t1n_ld;
   int n, h, w, M;
   int nt_store;
+  int out_even;     // patch form: store `out` at even (y, x) only (FCP_CHAIN_OUT_EVEN_ONLY)
 };
 
 // Pixels per workgroup tile: BMT = 128 (4 waves, up to two workgroups per CU; the default) or 256 (8 waves, one workgroup per
@@ -514,9 +515,13 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   unsigned so[2];                                                // byte offset of the two items in `out`, 0xFFFFFFFF past the end
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const long m = pix(erow0 + 16 * it);
+    const int prow = erow0 + 16 * it;
+    const long m = pix(prow);
     rm[it] = m >= 0 ? m : (long)p.M - 1;
-    so[it] = m >= 0 ? (unsigned)(m * p.out_ld * 4 + eq * 16) : 0xFFFFFFFFu;
+    // out_even: a stride-2 consumer reads even (y, x) only — patch origins are even, so the parity is that of the tile row;
+    // the dropped stores still issue (exact vmcnt), the hardware discards them: no HBM traffic
+    const bool keep = !PATCH || !p.out_even || ((((prow >> 4) | prow) & 1) == 0);
+    so[it] = (m >= 0 && keep) ? (unsigned)(m * p.out_ld * 4 + eq * 16) : 0xFFFFFFFFu;
   }
   __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
@@ -918,6 +923,8 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   k.n = d->n; k.h = d->h; k.w = d->w; k.M = (int)M;
   static const int nt_env = getenv("FCP_NT_STORE") ? atoi(getenv("FCP_NT_STORE")) : 1;
   k.nt_store = nt_env;
+  k.out_even = (d->flags & FCP_CHAIN_OUT_EVEN_ONLY) ? 1 : 0;
+  FCP_REQUIRE(!k.out_even || d->tile_m == 16, "chain: FCP_CHAIN_OUT_EVEN_ONLY needs the patch form (tile_m = 16)");
   hipStream_t s = (hipStream_t)stream;
   // tile height: 128 pixels / 4 waves (two independent workgroups per CU drift against each other: one's MFMAs beside the
   // other's epilogue); d->tile_m = 256 asks for the 8-wave form where the operand tile fits LDS and two waves per SIMD fit

@@ -128,7 +128,7 @@ std::tuple<Tensor, Tensor> bottleneck_chain(const Tensor& t1, int64_t t1_c0, con
                                             const c10::optional<Tensor>& w2, const c10::optional<Tensor>& ws2,
                                             const c10::optional<Tensor>& b2, const Tensor& w3, const Tensor& ws3,
                                             const Tensor& b3, const Tensor& w1n, const Tensor& ws1n, const Tensor& b1n,
-                                            int64_t c, int64_t nout, int64_t cn, int64_t tile_m) {
+                                            int64_t c, int64_t nout, int64_t cn, int64_t tile_m, int64_t flags) {
   dev(t1, "t1", at::kFloat);
   FCP_DEVICE_GUARD(t1);
   TORCH_CHECK(t1.dim() == 4 && t1_c0 + c <= t1.size(3), "t1 (n,h,w,>=c) split32 buffer");
@@ -148,7 +148,7 @@ std::tuple<Tensor, Tensor> bottleneck_chain(const Tensor& t1, int64_t t1_c0, con
   d.w3 = w3.data_ptr(); d.ws3 = dev(ws3, "ws3", at::kFloat).data_ptr<float>(); d.b3 = dev(b3, "b3", at::kFloat).data_ptr<float>();
   d.w1n = w1n.data_ptr(); d.ws1n = dev(ws1n, "ws1n", at::kFloat).data_ptr<float>(); d.b1n = dev(b1n, "b1n", at::kFloat).data_ptr<float>();
   d.n = (int)t1.size(0); d.h = (int)t1.size(1); d.w = (int)t1.size(2); d.c = (int)c; d.cn = (int)cn; d.nout = (int)nout;
-  d.t1_ld = (int)t1.size(3); d.out_ld = (int)nout; d.t1n_ld = (int)cn; d.tile_m = (int)tile_m;
+  d.t1_ld = (int)t1.size(3); d.out_ld = (int)nout; d.t1n_ld = (int)cn; d.tile_m = (int)tile_m; d.flags = (int)flags;
   ok(fcp_bottleneck_chain_f16x3(&d, cur_stream()), "fcp::bottleneck_chain");
   return {out, t1n};
 }
@@ -295,7 +295,7 @@ TORCH_LIBRARY(fcp, m) {
         "float alpha2, bool res1_pre, int precision, int in_fmt, int out_fmt, int res1_fmt, int res2_fmt, bool in_up2, "
         "bool cin4, int tile_m, int tile_n, Tensor? x2, int x2_c0, int cin2, int x2_stride, int flags, int cu_budget=0) -> ()");
   m.def("bottleneck_chain(Tensor t1, int t1_c0, Tensor? res, int res_c0, Tensor? w2, Tensor? ws2, Tensor? b2, Tensor w3, Tensor ws3, "
-        "Tensor b3, Tensor w1n, Tensor ws1n, Tensor b1n, int c, int nout, int cn, int tile_m=0) -> (Tensor, Tensor)");
+        "Tensor b3, Tensor w1n, Tensor ws1n, Tensor b1n, int c, int nout, int cn, int tile_m=0, int flags=0) -> (Tensor, Tensor)");
   m.def("retina_decode(Tensor head0, Tensor head1, Tensor head2, int img_h, int img_w, float vis, float var0, float var1) "
         "-> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("nms_select(Tensor cand_score, Tensor cand_box, Tensor cand_count, float nms_threshold, int strategy) "

@@ -601,13 +601,18 @@ CHAIN_TILE_M = int(os.environ.get("FCP_CHAIN_TILE_M", "0"))   # 0 / 128: 4-wave 
 # conv2 forms (layer 1): 8 x 16 pixel patches whose halo is staged once per channel slice (tile_m = 16 in the descriptor)
 # instead of 128 consecutive pixels fetched once per tap; same bits.  FCP_CHAIN_PATCH=0 = the linear tiles.
 CHAIN_PATCH = os.environ.get("FCP_CHAIN_PATCH", "1") != "0"
+# ... and a block whose output only a stride-2 consumer reads stores the even pixels only (bottleneck_chain(out_even_only=True))
+CHAIN_SPARSE_OUT = os.environ.get("FCP_CHAIN_SPARSE_OUT", "1") != "0"
 
 
 def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, t1: Act, res: Act | None,
-                     out: Act | None = None, t1n: Act | None = None, tile_m: int | None = None):
+                     out: Act | None = None, t1n: Act | None = None, tile_m: int | None = None, out_even_only: bool = False):
     """One launch for  out = relu(conv3(relu(conv2(t1))) [+ res]),  t1n = relu(conv1n(out))  (BatchNorm folded): conv2 /
     conv3 of a bottleneck and conv1 of the next block; ``pc2`` None: the pair forms (no conv2, see ``chain_supported``).
-    Bit-identical to the separate ``conv`` calls.  Returns (out, t1n), both split32."""
+    Bit-identical to the separate ``conv`` calls.  Returns (out, t1n), both split32.  ``out_even_only`` (conv2 forms on patch
+    tiles): ``out`` is only stored at pixels with even y and even x — for a block whose output nothing but a stride-2 consumer
+    reads (the other three quarters of the tensor are never written nor read; ``t1n`` is complete).  Ignored, i.e. a full
+    ``out``, where the patch form is not in use or a ``RangeMonitor`` wants to see the whole tensor."""
     assert chain_supported(pc2, pc3, pc1n, res is not None), "bottleneck_chain: unsupported shapes"
     assert t1.fmt == 1 and t1.c == pc3.cin and (res is None or (res.fmt == 1 and res.c == pc3.cout))
     assert res is None or (t1.n, t1.h, t1.w) == (res.n, res.h, res.w)
@@ -621,11 +626,12 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
     opt = lambda pc, f: None if pc is None else getattr(pc, f)
     if tile_m is None:
         tile_m = 16 if (pc2 is not None and CHAIN_PATCH and CHAIN_TILE_M == 0) else CHAIN_TILE_M
+    flags = N.CHAIN_OUT_EVEN_ONLY if (out_even_only and tile_m == 16 and CHAIN_SPARSE_OUT and RangeMonitor.active is None) else 0
     if T.ENABLED and out is None and t1n is None:
         # FCP_BOUNDARY=torch: the registered custom op allocates and returns both tensors
         o, t = T.load().bottleneck_chain(t1.buf, t1.c0, None if res is None else res.buf, 0 if res is None else res.c0,
                                          opt(pc2, "w"), opt(pc2, "wscale"), opt(pc2, "bias"), pc3.w, pc3.wscale, pc3.bias,
-                                         pc1n.w, pc1n.wscale, pc1n.bias, pc3.cin, pc3.cout, pc1n.cout, tile_m)
+                                         pc1n.w, pc1n.wscale, pc1n.bias, pc3.cin, pc3.cout, pc1n.cout, tile_m, flags)
         out, t1n = Act(o, fmt=1), Act(t, fmt=1)
     else:
         if out is None:
@@ -641,14 +647,15 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
         d.w1n, d.ws1n, d.b1n = N.ptr(pc1n.w), N.ptr(pc1n.wscale), N.ptr(pc1n.bias)
         d.n, d.h, d.w, d.c, d.cn, d.nout = t1.n, t1.h, t1.w, pc3.cin, pc1n.cout, pc3.cout
         d.t1_ld, d.res_ld, d.out_ld, d.t1n_ld = t1.ld, (res.ld if res is not None else 0), out.ld, t1n.ld
-        d.tile_m = tile_m
+        d.tile_m, d.flags = tile_m, flags
         N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
     if timing is not None:
         e1.record()
         c, nout, cn = pc3.cin, pc3.cout, pc1n.cout
-        byts = 4 * (m * (c + nout + (nout if res is not None else 0) + cn) + (0 if pc2 is None else 9 * c * c) + c * nout + nout * cn)
+        byts = 4 * (m * (c + (nout if not flags else nout // 4) + (nout if res is not None else 0) + cn) + (0 if pc2 is None else 9 * c * c)
+                    + c * nout + nout * cn)
         timing.append((e0, e1, flops, f"chain {'3x3 ' if pc2 is not None else ''}{c}->{nout}->{cn} @{t1.h}x{t1.w}"
-                       f"{' +res' if res is not None else ''}", byts))
+                       f"{' +res' if res is not None else ''}{' out@even' if flags else ''}", byts))
     if ConvStats.enabled:
         ConvStats.flops += flops
         ConvStats.launches += 1

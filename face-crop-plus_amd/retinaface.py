@@ -203,8 +203,11 @@ class RetinaFace:
             nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
             if (chain and blk["ds"] is None and not blk["feat"] and nxt is not None
                     and E.chain_supported(blk["c2"], blk["c3"], nxt["c1"])):
-                # conv2 + conv3 (+ identity) of this block and conv1 of the next one in one launch (layer 1)
-                x, pre = E.bottleneck_chain(blk["c2"], blk["c3"], nxt["c1"], o, x)   # pre: next block's conv1 output
+                # conv2 + conv3 (+ identity) of this block and conv1 of the next one in one launch (layer 1).  The last block
+                # of layer 1 feeds nothing but layer2.0 — whose conv1 is `pre` and whose 1x1 / 2 downsample (folded into its
+                # two-source conv3 below) samples x at even pixels only: three quarters of x need not be written
+                sparse = "c3ds" in nxt and nxt["c2"].stride == 2 and not blk["feat"]
+                x, pre = E.bottleneck_chain(blk["c2"], blk["c3"], nxt["c1"], o, x, out_even_only=sparse)   # pre: next block's conv1 output
                 continue
             if "c3ds" in blk and blk["c2"].stride == 1:
                 E.conv(blk["c2"], o, cat.slice(0, o.c), act_slope=0.0)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 12
+#define FCP_ABI_VERSION 13
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -162,7 +162,13 @@ typedef struct fcp_chain_desc {
                        * CU), 256 = 8-wave tiles where the operand tile fits LDS (the other forms keep 128), 16 = (conv2
                        * forms only) 4-wave tiles that are 8 x 16 pixel patches of one image, conv2's operand staged
                        * once per channel slice as the patch's halo.  Same bits whichever is chosen. */
+  int32_t flags;      /* FCP_CHAIN_OUT_EVEN_ONLY (patch form, tile_m = 16): `out` is stored at pixels with even y AND
+                       * even x only — for a block whose output is read by nothing but a stride-2 consumer (ResNet-50's
+                       * layer1.2: the next block's 1x1 / 2 downsample reads `out`, its conv1 is t1n, computed here): three
+                       * quarters of the tensor are never written nor read.  The other pixels of the buffer keep whatever
+                       * they held.  t1n is complete either way. */
 } fcp_chain_desc;
+#define FCP_CHAIN_OUT_EVEN_ONLY 1
 
 int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* desc, fcp_stream_t stream);
 

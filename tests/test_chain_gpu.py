@@ -136,3 +136,32 @@ def test_chain_rejects_unsupported_shapes(device):
         pc3 = E.pack_conv(torch.randn(2048, 512, 1, 1), torch.zeros(2048), None, 1, 0, device)
         pc1 = E.pack_conv(torch.randn(512, 2048, 1, 1), torch.zeros(512), None, 1, 0, device)
     assert not E.chain_supported(None, pc3, pc1)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 37, 45), (1, 16, 32), (3, 64, 50)])
+def test_chain_out_even_only(n, h, w, device):
+    """A block whose output only a stride-2 consumer reads (ResNet-50 layer1.2 -> layer2.0's 1x1 / 2 downsample) stores
+    `out` at even (y, x) only: those pixels and the complete t1n carry the bits of the full launch; nothing else is written."""
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(n * 77 + h)
+    mk = lambda co, ci, k: E.pack_conv(torch.randn(co, ci, k, k, generator=g) * (2 / (ci * k * k)) ** 0.5, torch.randn(co, generator=g) * 0.1,
+                                       None, 1, k // 2, device, precision="f16x3")
+    pc2, pc3, pc1 = mk(64, 64, 3), mk(256, 64, 1), mk(128, 256, 1)
+    t1 = E.f32_to_split32(E.Act(torch.randn(n, h, w, 64, generator=g).relu().to(device)))
+    x = E.f32_to_split32(E.Act(torch.randn(n, h, w, 256, generator=g).relu().to(device)))
+    full, t1n_full = E.bottleneck_chain(pc2, pc3, pc1, t1, x)
+    out = E.Act(torch.full((n, h, w, 256), -7.0, device=device), fmt=1)            # sentinel: untouched pixels keep it
+    t1n = E.Act.empty(n, h, w, 128, device, 1)
+    E.bottleneck_chain(pc2, pc3, pc1, t1, x, out, t1n, out_even_only=True)
+    torch.cuda.synchronize()
+    assert torch.equal(t1n.buf, t1n_full.buf)
+    assert torch.equal(out.buf[:, ::2, ::2], full.buf[:, ::2, ::2])
+    odd = torch.ones((h, w), dtype=torch.bool)
+    odd[::2, ::2] = False
+    assert bool((out.buf[:, odd.to(device)] == -7.0).all()), "a pixel the stride-2 consumer never reads was written"
+    # the stride-2 two-source consumer gives the same bits from the sparse tensor
+    pcd = mk(512, 128 + 256, 1)
+    o = E.f32_to_split32(E.Act(torch.randn(n, (h + 1) // 2, (w + 1) // 2, 128, generator=g).relu().to(device)))
+    a = E.conv(pcd, o, act_slope=0.0, out_fmt=1, x2=full, x2_stride=2)
+    b = E.conv(pcd, o, act_slope=0.0, out_fmt=1, x2=out, x2_stride=2)
+    assert torch.equal(a.buf, b.buf)
