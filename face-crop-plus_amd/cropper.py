@@ -324,7 +324,10 @@ class Cropper:
                         faces = self.crop_align(images, paddings, indices, landmarks)
                     faces_dev = torch.from_numpy(faces).to(self.device) if len(faces) else None
             else:
-                faces, faces_dev = images, None
+                # no alignment: the decoded images themselves are the "faces".  Inside process_dir they may be views of a
+                # decode worker's shared-memory ring, which is recycled as soon as this call returns, while the encode
+                # tasks run later: they get their own copies
+                faces, faces_dev = ([np.array(im) for im in images] if pinned is not None else images), None
             if self.par_model is not None and len(faces) > 0:
                 if faces_dev is None:
                     faces_dev = [torch.from_numpy(np.ascontiguousarray(f)).to(self.device) for f in faces]
@@ -410,8 +413,9 @@ class Cropper:
                     self._process_images(images, names, output_dir, pinned)
                     tls.stream.synchronize()
             finally:
-                # the batch has been uploaded (build_batch copies into pinned staging and waits for the copy) and every
-                # host-side use of the decoded images is over: their ring regions go back to the decode workers
+                # every use of the decoded images is over — the uploads out of the rings were enqueued before kernels whose
+                # results _process_images has read back (a stream synchronisation), the no-alignment path copied what it
+                # hands to the asynchronous writers — so their ring regions go back to the decode workers
                 del images
                 if procs is not None:
                     procs.release(tokens)
@@ -457,6 +461,7 @@ class Cropper:
         want = self.io_processes
         if want is None:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+            cores //= max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))      # one process per GPU: share the host
             # measured on a 2 x 64-core EPYC 9575F box (2048 JPEGs of 640^2, one decode request per decoder and batch;
             # 2 / 3 GPU workers): (8, 3) 2320 / 2650, (12, 3) 2360 / 2750, (12, 4) 2300 / 2540, (16, 4) 2270 / 2600,
             # (24, 4) 2110 / 2650 images/s — flat beyond a dozen decoders (one decodes ~600 images/s)
