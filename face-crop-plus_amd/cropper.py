@@ -79,6 +79,7 @@ class Cropper:
         # Pillow work leaves the parent's interpreter lock.  (readers, writers); None = sized from the host's cores;
         # FCP_IO_PROCESSES=0 (or io_processes = (0, 0)) keeps decode / encode on the threads
         self.io_processes = (0, 0) if os.environ.get("FCP_IO_PROCESSES", "1") == "0" else None
+        self.io_ring_mb = None       # shared-memory ring of a decode worker in MiB (None: FCP_IO_RING_MB, default 128)
         self._io_procs = None
         # set by process_dir as ONE tuple (executor the encoded files are written on, futures of the writes still in
         # flight, semaphore bounding them), so that a task of a failed run can never see a half-reset state
@@ -475,7 +476,8 @@ class Cropper:
             have.close()
         try:
             from ._io_pool import IOProcesses
-            self._io_procs = IOProcesses(*want, register=self._pin_ring if os.environ.get("FCP_IO_PIN", "1") != "0" else None)
+            kw = {} if getattr(self, "io_ring_mb", None) is None else {"ring_mb": int(self.io_ring_mb)}
+            self._io_procs = IOProcesses(*want, register=self._pin_ring if os.environ.get("FCP_IO_PIN", "1") != "0" else None, **kw)
         except (ValueError, OSError) as e:           # no memfd / no processes left on this host: threads still work
             import warnings
             warnings.warn(f"decode / encode worker processes unavailable ({e}): using I/O threads")

@@ -270,7 +270,7 @@ def test_two_croppers_two_threads_one_device(tmp_path, device):
     assert len(outs["solo"]) > 8 and outs["a"] == outs["b"] == outs["solo"]
 
 
-def test_process_dir_without_detector_copies_borrowed_images(tmp_path, device, monkeypatch):
+def test_process_dir_without_detector_copies_borrowed_images(tmp_path, device):
     """det_threshold=None and no landmarks: the decoded images themselves are written.  With decode worker processes they are
     views of recycled shared-memory rings while the encoders run asynchronously: the output must still equal the thread
     pipeline's, file for file (a tiny ring forces recycling inside the run)."""
@@ -283,11 +283,8 @@ def test_process_dir_without_detector_copies_borrowed_images(tmp_path, device, m
         Image.fromarray(rng.integers(0, 256, (120, 150, 3), dtype=np.uint8)).save(src / f"p{i:02d}.png")
     outs = {}
     for tag, procs in (("threads", (0, 0)), ("procs", (2, 1))):
-        monkeypatch.setenv("FCP_IO_RING_MB", "1")
-        import importlib, face_crop_plus_amd._io_pool as IP
-        importlib.reload(IP)                                     # RING_MB is read at import
         c = Cropper(det_threshold=None, batch_size=4, device="cuda:0", output_format="png")
-        c.io_processes = procs
+        c.io_processes, c.io_ring_mb = procs, 1
         c.process_dir(str(src), str(tmp_path / tag), desc=None)
         outs[tag] = {f: (tmp_path / tag / f).read_bytes() for f in sorted(os.listdir(tmp_path / tag))}
     assert len(outs["threads"]) == 24 and outs["threads"] == outs["procs"]
