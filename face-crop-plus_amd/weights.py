@@ -251,8 +251,13 @@ def load_state_dict(model: str, source=None, seed: int = 0, device=None):
             sd = load_local(model, source, seed)
         except Exception as e:                       # noqa: BLE001 - reported on every rank below
             err = f"{type(e).__name__}: {e}"
+    if dist.get_backend() == "nccl":                 # RCCL moves device tensors only: this rank's GPU for objects and weights alike
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+    else:
+        device = None                                # gloo (CPU tests; two ranks sharing one GPU): host tensors
     status = [err]
-    dist.broadcast_object_list(status, src=0)
+    dist.broadcast_object_list(status, src=0, device=device)
     if status[0] is not None:
         raise RuntimeError(f"{model}: rank 0 could not load the weights it was to broadcast: {status[0]}")
     names = [(n, tuple(shp)) for n, shp, _ in SPECS[model]()]
@@ -261,10 +266,6 @@ def load_state_dict(model: str, source=None, seed: int = 0, device=None):
     else:                                            # same keys and shapes everywhere: the spec is the skeleton
         sd = {n: (torch.zeros(shp, dtype=torch.float32) if not n.endswith("num_batches_tracked") else torch.tensor(0))
               for n, shp in names}
-    if device is None and dist.get_backend() == "nccl":
-        device = torch.device("cuda", torch.cuda.current_device())
-    elif dist.get_backend() != "nccl":
-        device = None                                # gloo (CPU tests; two ranks sharing one GPU): host tensors
     return _validated(model, D.broadcast_state_dict(sd, device))
 
 
