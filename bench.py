@@ -512,6 +512,7 @@ def main():
                  seed=1234 + rank, graph=args.graph, sd_enh=sds.get("rrdb"), sd_par=sds.get("bisenet"))
     live = rank == 0 and args.streams <= 1 and not args.graph
     elapsed, faces = time_pipeline(p, args.steps, args.warmup, autotune=not args.no_autotune, dist=dist, live_events=live)
+    last_timed = p.last                            # outputs of the LAST TIMED step (the roofline passes below overwrite p.last)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -532,7 +533,7 @@ def main():
             except Exception as e:                       # a side record must never take the headline line down
                 hbm_kernels = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline, parity_check = run_cpu_baseline(sd, p.images[:32].cpu(), args, p.tgt.cpu().numpy(), p.last)
+        cpu_baseline, parity_check = run_cpu_baseline(sd, p.images[:32].cpu(), args, p.tgt.cpu().numpy(), last_timed)
     describe = p.describe()
     if rank == 0 and world == 1 and not args.no_extra and not full:
         del p
