@@ -1,0 +1,50 @@
+"""bench.py's own plumbing that needs no GPU: the launcher guard of --gpus N and the oracle checker of the timed batch."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gpus_n_without_devices_fails_loudly_instead_of_running_one_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "refusing to run 2 ranks" in r.stderr + r.stdout
+    assert '"metric"' not in r.stdout                       # no JSON line from a silent 1-rank run
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")   # a launcher that started the wrong number of ranks
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr + r.stdout
+
+
+def test_parity_checker_accepts_the_oracle_and_rejects_a_shifted_landmark(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import align_ref as A
+    rng = np.random.default_rng(4)
+    k, out = 3, 32
+    images = torch.from_numpy(rng.integers(0, 256, (k + 1, 96, 96, 3), dtype=np.uint8))
+    tgt = A.landmarks_target((out, out), 0.65)
+    # one face per image: a similarity image of the target somewhere inside the picture
+    lm = np.stack([tgt * 1.4 + np.array([10.0 + 5 * i, 14.0]) for i in range(k + 1)]).astype(np.float32)
+    idx = list(range(k + 1))
+    crops = A.crop_align(images.numpy(), None, idx, lm, tgt, (out, out), "constant")
+    last = ({"face_offset": torch.tensor([0, 1, 2, 3, 4]), "img_idx": torch.tensor(idx, dtype=torch.int32), "landmarks": torch.from_numpy(lm)},
+            torch.from_numpy(crops), torch.ones(k + 1, dtype=torch.int32))
+    rec = bench.check_against_oracle(last, images, k, lm[:k], idx[:k], tgt, out, A)
+    assert rec["indices_equal"] and rec["faces"] == k and rec["max_landmark_err_px"] == 0.0 and rec["crop_bytes_differing"] == 0
+    assert rec["crop_bytes_compared"] == k * out * out * 3
+    for breakage in ("landmark", "index", "crop"):
+        lm_ref, idx_ref, bad = lm[:k].copy(), idx[:k], last
+        if breakage == "landmark":
+            lm_ref[1, 2, 0] += 0.01                        # 1e-2 px from the oracle: above the 1e-3 tolerance
+        elif breakage == "index":
+            idx_ref = [0, 2, 2]
+        else:
+            c2 = crops.copy(); c2[0, 5, 5, 1] ^= 1
+            bad = (last[0], torch.from_numpy(c2), last[2])
+        with pytest.raises(SystemExit, match="does not match the oracle"):
+            bench.check_against_oracle(bad, images, k, lm_ref, idx_ref, tgt, out, A)

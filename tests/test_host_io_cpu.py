@@ -189,3 +189,16 @@ def test_bounded_async_writes(tmp_path, monkeypatch):
     with pytest.raises(OSError, match="disk full"):
         c._emit(str(tmp_path / "next.png"), np.zeros((2, 2, 3), np.uint8))
     c._io[0].shutdown(wait=True)
+
+
+def test_selfcheck_mode_policy(monkeypatch):
+    """The range guard runs by itself for weights that come from a checkpoint, never for in-memory / generated ones,
+    and FCP_SELFCHECK overrides both ways."""
+    from face_crop_plus_amd import engine as E
+    monkeypatch.delenv("FCP_SELFCHECK", raising=False)
+    assert E.selfcheck_mode(None) and E.selfcheck_mode("/some/retinaface_detector.pth")
+    assert not E.selfcheck_mode("generated") and not E.selfcheck_mode({"a": 1})
+    monkeypatch.setenv("FCP_SELFCHECK", "0")
+    assert not E.selfcheck_mode(None)
+    monkeypatch.setenv("FCP_SELFCHECK", "1")
+    assert E.selfcheck_mode("generated") and E.selfcheck_mode({"a": 1})
