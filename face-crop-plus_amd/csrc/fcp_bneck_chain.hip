@@ -103,7 +103,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false>
 __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT / 128) bneck_chain_c64(const ChainK p) {
   static_assert(!HAS_C2 || CW == C, "phase 1 is written for 64-channel bottlenecks");
-  static_assert(!PATCH || (HAS_C2 && BMT == 128), "the patch form is the 128-pixel conv2 form");
+  static_assert(!PATCH || HAS_C2, "the patch form is a conv2 form");
+  constexpr int PH = BMT / 16;                      // PATCH: rows of the (PH x 16)-pixel patch: 8 (4 waves) or 16 (8 waves)
   static_assert(BMT == 128 || BMT == 256, "tile height");
   constexpr int NTHR = 2 * BMT;                     // threads: one wave per 32 rows
   constexpr int NW = NTHR / 64;                     // waves
@@ -166,11 +167,11 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   // tile row -> pixel index in (n, h, w) order, or -1 for a row that has no pixel (past the end / outside the image)
   int pn = 0, py0 = 0, px0 = 0;                                  // PATCH: image and top-left pixel of the 8 x 16 patch
   if constexpr (PATCH) {
-    const int txn = (p.w + 15) >> 4, tyn = (p.h + 7) >> 3;
+    const int txn = (p.w + 15) >> 4, tyn = (p.h + PH - 1) / PH;
     const int r = tile_m / txn;
     px0 = (tile_m - r * txn) * 16;
     pn = r / tyn;
-    py0 = (r - pn * tyn) * 8;
+    py0 = (r - pn * tyn) * PH;
   }
   auto pix = [&](int row) -> long {
     if constexpr (PATCH) {
@@ -226,7 +227,8 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
 
   // =========================================================================================== phase 1: 3x3 conv
   if constexpr (HAS_C2 && PATCH) {
-    constexpr int HROWS = 192;                                   // 10 x 18 = 180 halo rows, padded to whole DMA passes
+    constexpr int HALO = (PH + 2) * 18;                          // 10 x 18 = 180 | 18 x 18 = 324 halo rows ...
+    constexpr int HROWS = (HALO + LR - 1) / LR * LR;             // ... padded to whole DMA passes: 192 | 384
     constexpr int ASL = HROWS * ROWB;                            // one channel slice of the halo patch: 24 KiB
     constexpr int BST_OFF = 2 * ASL, BSTG = C * ROWB;            // two 8 KiB filter stages behind the two slices
     static_assert(BST_OFF + 2 * BSTG <= T2_OFF + BMT * C * 4, "halo patch + filter stages must fit region 0 + T2");
@@ -240,7 +242,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
       const int r = lrow + LR * i;
       const int hy = r / 18, hx = r - hy * 18;
       const int y = py0 - 1 + hy, x = px0 - 1 + hx;
-      const bool ok = r < 180 && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
+      const bool ok = r < HALO && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
       const unsigned src = ok ? ((unsigned)((pn * p.h + y) * p.w + x) * (unsigned)p.t1_ld + (unsigned)(csrc * 4)) * 4u : 0xFFFFFFFFu;
 #pragma unroll
       for (int cs = 0; cs < 2; ++cs)
@@ -877,7 +879,7 @@ template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PAT
 int launch(const ChainK& k, hipStream_t s) {
   constexpr int LDS = lds_bytes(BMT, CW, CN, HAS_C2);
   FCP_LDS_OPT_IN((&bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH>), LDS);
-  const int tiles = PATCH ? k.n * ((k.h + 7) >> 3) * ((k.w + 15) >> 4) : fcp_cdiv(k.M, BMT);
+  const int tiles = PATCH ? k.n * fcp_cdiv(k.h, BMT / 16) * ((k.w + 15) >> 4) : fcp_cdiv(k.M, BMT);
   hipLaunchKernelGGL((bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH>), dim3(tiles), dim3(2 * BMT), LDS, s, k);
   FCP_LAUNCH_OK();
   return 0;
@@ -924,7 +926,7 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   static const int nt_env = getenv("FCP_NT_STORE") ? atoi(getenv("FCP_NT_STORE")) : 1;
   k.nt_store = nt_env;
   k.out_even = (d->flags & FCP_CHAIN_OUT_EVEN_ONLY) ? 1 : 0;
-  FCP_REQUIRE(!k.out_even || d->tile_m == 16, "chain: FCP_CHAIN_OUT_EVEN_ONLY needs the patch form (tile_m = 16)");
+  FCP_REQUIRE(!k.out_even || d->tile_m == 16 || d->tile_m == 32, "chain: FCP_CHAIN_OUT_EVEN_ONLY needs a patch form (tile_m = 16 | 32)");
   hipStream_t s = (hipStream_t)stream;
   // tile height: 128 pixels / 4 waves (two independent workgroups per CU drift against each other: one's MFMAs beside the
   // other's epilogue); d->tile_m = 256 asks for the 8-wave form where the operand tile fits LDS and two waves per SIMD fit
@@ -932,11 +934,12 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   // waves loses — profiles/r03_probes.md)
   const bool big = d->tile_m == 256;
   // d->tile_m = 16: the conv2 forms on 8 x 16 patches with a staged halo (PATCH; same bits)
-  const bool patch = d->tile_m == 16;
-  FCP_REQUIRE(!patch || has_c2, "chain: tile_m = 16 (8 x 16 patches) exists for the conv2 forms only");
+  // d->tile_m = 32: the same with 16 x 16 patches on 8 waves (one workgroup per CU; every filter byte serves 256 pixels)
+  const bool patch = d->tile_m == 16, patch2 = d->tile_m == 32;
+  FCP_REQUIRE(!(patch || patch2) || has_c2, "chain: tile_m = 16 / 32 (pixel patches) exist for the conv2 forms only");
   switch (variant) {
-    case 1: return patch ? launch<64, 64, 256, true, true, 128, true>(k, s) : big ? launch<64, 64, 256, true, true, 256>(k, s) : launch<64, 64, 256, true, true, 128>(k, s);
-    case 2: return patch ? launch<128, 64, 256, true, true, 128, true>(k, s) : big ? launch<128, 64, 256, true, true, 256>(k, s) : launch<128, 64, 256, true, true, 128>(k, s);
+    case 1: return patch2 ? launch<64, 64, 256, true, true, 256, true>(k, s) : patch ? launch<64, 64, 256, true, true, 128, true>(k, s) : big ? launch<64, 64, 256, true, true, 256>(k, s) : launch<64, 64, 256, true, true, 128>(k, s);
+    case 2: return patch2 ? launch<128, 64, 256, true, true, 256, true>(k, s) : patch ? launch<128, 64, 256, true, true, 128, true>(k, s) : big ? launch<128, 64, 256, true, true, 256>(k, s) : launch<128, 64, 256, true, true, 128>(k, s);
     case 3: return big ? launch<128, 128, 512, false, true, 256>(k, s) : launch<128, 128, 512, false, true, 128>(k, s);
     case 5: return launch<256, 256, 1024, false, true, 128>(k, s);
     case 6: return launch<256, 128, 512, false, true, 128>(k, s);     // CN = 256: 128 accumulator registers, one wave per SIMD only

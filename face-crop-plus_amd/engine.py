@@ -625,8 +625,8 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
         e0.record()
     opt = lambda pc, f: None if pc is None else getattr(pc, f)
     if tile_m is None:
-        tile_m = 16 if (pc2 is not None and CHAIN_PATCH and CHAIN_TILE_M == 0) else CHAIN_TILE_M
-    flags = N.CHAIN_OUT_EVEN_ONLY if (out_even_only and tile_m == 16 and CHAIN_SPARSE_OUT and RangeMonitor.active is None) else 0
+        tile_m = 16 if (pc2 is not None and CHAIN_PATCH and CHAIN_TILE_M == 0) else (CHAIN_TILE_M if (pc2 is not None or CHAIN_TILE_M not in (16, 32)) else 0)
+    flags = N.CHAIN_OUT_EVEN_ONLY if (out_even_only and tile_m in (16, 32) and CHAIN_SPARSE_OUT and RangeMonitor.active is None) else 0
     if T.ENABLED and out is None and t1n is None:
         # FCP_BOUNDARY=torch: the registered custom op allocates and returns both tensors
         o, t = T.load().bottleneck_chain(t1.buf, t1.c0, None if res is None else res.buf, 0 if res is None else res.c0,

@@ -161,7 +161,8 @@ typedef struct fcp_chain_desc {
   int32_t tile_m;     /* pixels per workgroup tile: 0 / 128 = 4-wave tiles of 128 consecutive pixels (two workgroups per
                        * CU), 256 = 8-wave tiles where the operand tile fits LDS (the other forms keep 128), 16 = (conv2
                        * forms only) 4-wave tiles that are 8 x 16 pixel patches of one image, conv2's operand staged
-                       * once per channel slice as the patch's halo.  Same bits whichever is chosen. */
+                       * once per channel slice as the patch's halo; 32 = the same on 8 waves and 16 x 16 patches (one
+                       * workgroup per CU).  Same bits whichever is chosen. */
   int32_t flags;      /* FCP_CHAIN_OUT_EVEN_ONLY (patch form, tile_m = 16): `out` is stored at pixels with even y AND
                        * even x only — for a block whose output is read by nothing but a stride-2 consumer (ResNet-50's
                        * layer1.2: the next block's 1x1 / 2 downsample reads `out`, its conv1 is t1n, computed here): three

@@ -45,7 +45,7 @@ def test_chain_equals_three_convs(n, h, w, cn, device):
     torch.cuda.synchronize()
     assert torch.equal(out.buf, o3.buf), "fused conv3 output differs from the stand-alone kernels"
     assert torch.equal(t1n.buf, o1.buf), "fused next-conv1 output differs from the stand-alone kernels"
-    for tm in (128, 16, 256):                                              # linear 4-wave tiles, patches, 8-wave tiles: same bits
+    for tm in (128, 16, 256, 32):                                          # linear 4-wave tiles, 8 x 16 patches, 8-wave tiles, 16 x 16 patches: same bits
         o_t, t_t = E.bottleneck_chain(pc2, pc3, pc1, t1a, xa, tile_m=tm)
         assert torch.equal(o_t.buf, o3.buf) and torch.equal(t_t.buf, o1.buf), f"tile_m={tm}"
     # and against torch fp32

@@ -34,7 +34,9 @@ for cn in (64, 128):
     tc = timeit(lambda: E.bottleneck_chain(pc2, pc3, pc1, t1, x, out, t1n))
     tl = timeit(lambda: E.bottleneck_chain(pc2, pc3, pc1, t1, x, out, t1n, tile_m=128))
     tp = timeit(lambda: E.bottleneck_chain(pc2, pc3, pc1, t1, x, out, t1n, tile_m=16))
-    print(f"cn={cn}: linear 128-pixel tiles {tl:7.1f} us, 8 x 16 patches {tp:7.1f} us", flush=True)
+    tp2 = timeit(lambda: E.bottleneck_chain(pc2, pc3, pc1, t1, x, out, t1n, tile_m=32))
+    tl2 = timeit(lambda: E.bottleneck_chain(pc2, pc3, pc1, t1, x, out, t1n, tile_m=256))
+    print(f"cn={cn}: linear 128-pixel tiles {tl:7.1f} us, 8 x 16 patches {tp:7.1f} us, linear 256 {tl2:7.1f} us, 16 x 16 patches {tp2:7.1f} us", flush=True)
     t2 = timeit(lambda: E.conv(pc2, t1, o2, act_slope=0.0))
     t3 = timeit(lambda: E.conv(pc3, o2, out, act_slope=0.0, res1=x))
     t1_ = timeit(lambda: E.conv(pc1, out, t1n, act_slope=0.0))

@@ -26,6 +26,8 @@ for case in range(cases):
     out, t1n = E.bottleneck_chain(pc2, pc3, pc1, t, xr)                      # 128-pixel tiles, 4 waves
     out4, t1n4 = E.bottleneck_chain(pc2, pc3, pc1, t, xr, tile_m=256)        # and the 8-wave form (where supported)
     outl, t1nl = E.bottleneck_chain(pc2, pc3, pc1, t, xr, tile_m=128)        # linear 128-pixel tiles (the default of the conv2 forms is the patch form)
+    if has_c2:
+        out4, t1n4 = E.bottleneck_chain(pc2, pc3, pc1, t, xr, tile_m=32) if case % 2 else (out4, t1n4)   # 16 x 16 patches on 8 waves
     torch.cuda.synchronize()
     if not (torch.equal(out.buf, o3.buf) and torch.equal(t1n.buf, o1.buf) and torch.equal(out4.buf, o3.buf) and torch.equal(t1n4.buf, o1.buf)
             and torch.equal(outl.buf, o3.buf) and torch.equal(t1nl.buf, o1.buf)):
