@@ -230,7 +230,12 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     constexpr int HALO = (PH + 2) * 18;                          // 10 x 18 = 180 | 18 x 18 = 324 halo rows ...
     constexpr int HROWS = (HALO + LR - 1) / LR * LR;             // ... padded to whole DMA passes: 192 | 384
     constexpr int ASL = HROWS * ROWB;                            // one channel slice of the halo patch: 24 KiB
-    constexpr int BST_OFF = 2 * ASL, BSTG = C * ROWB;            // two 8 KiB filter stages behind the two slices
+    // filter stages behind the two slices: TPB taps (K slices of 8 KiB) per stage and per workgroup barrier — 2 where the
+    // patch form runs two workgroups per CU in 80 KiB, 3 in the 8-wave form
+    // (one tap per barrier measured equal in the 4-wave form and 3.5-4 % slower in the 8-wave form: profiles/r04_probes.md 1e)
+    constexpr int TPB = BMT == 128 ? 2 : 3, NSTEP = 18 / TPB;
+    static_assert(18 % TPB == 0, "taps per barrier must divide the 18 K slices");
+    constexpr int BST_OFF = 2 * ASL, BSL = C * ROWB, BSTG = TPB * BSL;
     static_assert(BST_OFF + 2 * BSTG <= T2_OFF + BMT * C * 4, "halo patch + filter stages must fit region 0 + T2");
     f32x16 acc1[2];
     const int wm = wave / 2, wn = wave % 2;                      // 2 x 2 waves of 64 x 32, as in the linear form
@@ -253,11 +258,13 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     unsigned woff[B_LD];
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) woff[i] = (unsigned)(((lrow + LR * i) * (9 * C) + csrc * 4) * 4);
-    auto dma_b = [&](int kt, int stage) {
+    auto dma_b = [&](int step, int stage) {                      // the TPB K slices of a step
 #pragma unroll
-      for (int i = 0; i < B_LD; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + BST_OFF + stage * BSTG + (wave_u * 8 + LR * i) * ROWB), 16,
-                                                 (int)(woff[i] + (unsigned)(kt * BK * 4)), 0, 0, 0);
+      for (int u = 0; u < TPB; ++u)
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + BST_OFF + stage * BSTG + u * BSL + (wave_u * 8 + LR * i) * ROWB), 16,
+                                                   (int)(woff[i] + (unsigned)((step * TPB + u) * BK * 4)), 0, 0, 0);
     };
     dma_b(0, 0);
 #pragma unroll
@@ -269,15 +276,15 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
 #pragma unroll
     for (int i = 0; i < 2; ++i) hr0[i] = (wm * 4 + i * 2 + (l31 >> 4)) * 18 + (l31 & 15);
     const char* Bw = lds + BST_OFF + (wn * 32 + l31) * ROWB;
-    for (int cs = 0; cs < 2; ++cs) {
-      static_for<0, 9>([&](auto tc) {
-        constexpr int tap = decltype(tc)::value;
-        const int kt = cs * 9 + tap;
-        // filter slice kt has landed (with the halo patch, at kt = 0) and every wave has read slice kt - 1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const char* Bb = Bw + (kt & 1) * BSTG;
+    static_for<0, NSTEP>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      // the filter slices of step g have landed (with the halo patch, at g = 0) and every wave has read those of step g - 1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, TPB>([&](auto uc) {
+        constexpr int kt = g * TPB + decltype(uc)::value, cs = kt / 9, tap = kt % 9;   // K order: channel slice outer, taps inner
+        const char* Bb = Bw + (g & 1) * BSTG + decltype(uc)::value * BSL;
         f16x8 ah[2][2], al[2][2], bh[2], bl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -295,10 +302,14 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
           bh[sq] = *reinterpret_cast<const f16x8*>(Bb + offH[sq]);
           bl[sq] = *reinterpret_cast<const f16x8*>(Bb + offL[sq]);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < 18) dma_b(kt + 1, (kt + 1) & 1);            // into the stage slice kt - 1 has left
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(uc)::value == TPB - 1) {
+          // the step's last fragment reads are out: the next step's filters may go into the stage step g - 1 has left.
+          // (Issued behind ALL LDS reads of the step: the compiler drains pending LDS-DMA in front of an LDS read.)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (g + 1 < NSTEP) dma_b(g + 1, (g + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int sq = 0; sq < 2; ++sq)
 #pragma unroll
@@ -309,7 +320,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
           }
         __builtin_amdgcn_sched_barrier(0);
       });
-    }
+    });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                  // every wave has consumed the last slice: patch and stages are dead
     __builtin_amdgcn_sched_barrier(0);
