@@ -107,3 +107,26 @@ def test_read_many_one_reply_keeps_order_with_unreadable_and_oversize_files(pool
             assert np.array_equal(arr, imgs[name]), name
     assert [tok is not None for _, tok in got] == [True, False, False, True, True]
     pool.release([tok for _, tok in got])
+
+
+def test_workers_exit_when_the_parent_dies_without_closing(tmp_path):
+    """Workers hold only their own descriptors (subprocess + pass_fds): when the parent is gone — killed, crashed — their
+    socket reads end and they leave; no orphan decoder keeps a box busy."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from face_crop_plus_amd._io_pool import IOProcesses\n"
+            "p = IOProcesses(2, 1, ring_mb=1)\n"
+            "print(' '.join(str(w.proc.pid) for w in p._readers + p._writers), flush=True)\n"
+            "os._exit(0)\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    pids = [int(x) for x in out.stdout.split()]
+    assert len(pids) == 3, out.stderr
+    deadline = time.time() + 10
+    alive = pids
+    while alive and time.time() < deadline:
+        alive = [pid for pid in alive if os.path.exists(f"/proc/{pid}") and "Z" not in open(f"/proc/{pid}/stat").read().split(")")[1].split()[0]]
+        time.sleep(0.1)
+    assert not alive, f"worker processes {alive} survived their parent"
