@@ -557,6 +557,11 @@ def main():
             "roofline": roofline, "hbm_kernels": hbm_kernels, "cpu_baseline": cpu_baseline,
             "parity_check": parity_check,
         }
+        if isinstance(hbm_kernels, dict) and roofline is not None:
+            # SURVEY 8(d) "HBM GB/s for the non-conv kernels", compactly inside `roofline` as well (the full records stay in
+            # `hbm_kernels`): kernel -> [us per launch, algorithmic GB/s, fraction of the 8 TB/s peak]
+            roofline["hbm_bound_kernels"] = {k: [v["avg_launch_us"], v["achieved"], v["frac"]] for k, v in hbm_kernels.items()
+                                             if isinstance(v, dict) and "achieved" in v}
         if extra is not None:
             line["extra"] = extra
             # the north-star geometry (batch 32 @1024^2, detect + align + crop: the per-GPU rate that decides >= 10 k
