@@ -470,6 +470,9 @@ def main():
     global LAUNCH_TABLE, AUTOTUNE_ROOFLINE
     LAUNCH_TABLE = args.launch_table
     AUTOTUNE_ROOFLINE = not args.no_autotune and os.environ.get("FCP_AUTOTUNE", "1") != "0"
+    if not AUTOTUNE_ROOFLINE:
+        from face_crop_plus_amd import engine as _E
+        _E.Autotune.use_tables = False              # heuristic tiles: neither tuning launches nor the shipped / user tables
     full = args.workload == "full"
     if args.batch is None:
         args.batch = 32 if full else 64
@@ -500,13 +503,25 @@ def main():
 
     from face_crop_plus_amd import weights
 
-    sd = weights.generate_state_dict("retinaface")
+    # Every network the workload runs comes from rank 0 through one flat RCCL broadcast each (north_star: "RCCL broadcast of
+    # weights + per-rank independent batches"; 228.9 MB for the three) — what the product's loader
+    # (weights.load_state_dict) does inside a process group.  The other ranks' generated copies are only the key / shape
+    # templates the flat buffer is cut by; broadcast_state_dict zeroes them before the collective.
+    names = ["retinaface"] + (["rrdb", "bisenet"] if full else [])
+    sds = {k: weights.generate_state_dict(k) for k in names}
+    broadcast = None
     if dist is not None:
         from face_crop_plus_amd.dist import broadcast_state_dict
-        sd = broadcast_state_dict(sd, dev)        # rank 0's weights -> all ranks, one flat RCCL broadcast
-    sds = {"retinaface": sd}
-    if full:
-        sds["rrdb"], sds["bisenet"] = weights.generate_state_dict("rrdb"), weights.generate_state_dict("bisenet")
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        nbytes = 0
+        for k in names:
+            sds[k] = broadcast_state_dict(sds[k], dev)
+            nbytes += sum(4 * v.numel() for kk, v in sds[k].items() if not kk.endswith("num_batches_tracked"))
+        torch.cuda.synchronize()
+        broadcast = {"networks": names, "bytes": int(nbytes), "ms": round((time.perf_counter() - tb) * 1e3, 2),
+                     "note": "one flat fp32 RCCL broadcast per network from rank 0, incl. the host-side flatten / H2D / D2H / unflatten"}
+    sd = sds["retinaface"]
     p = Pipeline(dev, sd, full=full, batch=args.batch, size=args.size, out_size=args.out_size, strategy=args.strategy,
                  precision=args.precision, enhance=args.enhance if full else "none", streams=args.streams,
                  seed=1234 + rank, graph=args.graph, sd_enh=sds.get("rrdb"), sd_par=sds.get("bisenet"))
@@ -557,6 +572,9 @@ def main():
             "roofline": roofline, "hbm_kernels": hbm_kernels, "cpu_baseline": cpu_baseline,
             "parity_check": parity_check,
         }
+        if broadcast is not None:
+            line["weight_broadcast"] = broadcast
+            line["config"]["broadcast_bytes"], line["config"]["broadcast_ms"] = broadcast["bytes"], broadcast["ms"]
         if isinstance(hbm_kernels, dict) and roofline is not None:
             # SURVEY 8(d) "HBM GB/s for the non-conv kernels", compactly inside `roofline` as well (the full records stay in
             # `hbm_kernels`): kernel -> [us per launch, algorithmic GB/s, fraction of the 8 TB/s peak]
@@ -572,7 +590,19 @@ def main():
                     "workload": ns["workload"], "value": ns["value"], "unit": ns["unit"], "ms_per_step": ns["ms_per_step"],
                     "steps": ns["steps"], "warmup": ns["warmup"], "roofline_frac": ns["roofline"]["frac"],
                     "roofline_frac_timed": ns["roofline"].get("frac_timed")}
-                line["roofline"]["north_star_geometry_frac"] = ns["roofline"]["frac"]
+                # ... and as scalars (consumers that flatten nested records keep scalars only): the north-star metric
+                # "faces/sec on synthetic 1024x1024 RGB batches" (batch 32, detect + align + crop, one GPU)
+                for where in (line["roofline"], line["config"]):
+                    where["north_star_geometry_value"] = ns["value"]
+                    where["north_star_geometry_unit"] = "faces/s, batch 32 @1024x1024, detect+align+crop, 1 GPU"
+                    where["north_star_geometry_ms_per_step"] = ns["ms_per_step"]
+                    where["north_star_geometry_steps"] = ns["steps"]
+                    where["north_star_geometry_frac"] = ns["roofline"]["frac"]
+                    where["north_star_geometry_frac_timed"] = ns["roofline"].get("frac_timed")
+        # the long side records first, the contract fields last: a consumer that keeps only the tail of the line sees the
+        # headline, `config`, `roofline` and `cpu_baseline`
+        first = [k for k in ("extra", "hbm_kernels", "parity_check", "weight_broadcast") if k in line]
+        line = {**{k: line[k] for k in first}, **{k: v for k, v in line.items() if k not in first}}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -605,6 +635,19 @@ def host_cores():
     except Exception:
         pass
     return n
+
+
+def cpu_model():
+    """Model name of the host CPU (BASELINE.md section 4 asks for the CPU model and core count beside the CPU baseline)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def pick_cpu_threads():
@@ -648,7 +691,10 @@ def run_cpu_baseline(sd, images_u8, args, tgt, last=None):
     t1, _, _, _ = run(1)                 # warm-up + per-image cost estimate
     k = int(max(2, min(images_u8.shape[0], args.cpu_seconds / max(t1, 1e-3))))
     t, nf, lm_ref, idx_ref = run(k)
-    base = {"value": round(nf / t, 3), "unit": "faces/s", "cores": cores, "kind": "port",
+    base = {"value": round(nf / t, 3), "unit": "faces/s", "cores": cores, "host_cores": host_cores(),
+            "host_logical_cpus": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port",
+            "cores_note": "cores = torch threads the oracle ran on (the fastest of a short conv probe: oversubscribed boxes get "
+                          "slower with every core); host_cores = cores this process may use (affinity mask / cgroup quota)",
             "sample": f"{k} images of the same synthetic {args.size}x{args.size} batch, torch-CPU fp32 + numpy oracle, "
                       f"{t:.1f} s wall"}
     return base, (check_against_oracle(last, images_u8, k, lm_ref, idx_ref, tgt, args.out_size, A) if last is not None else None)
@@ -672,7 +718,9 @@ def check_against_oracle(last, images_u8, k, lm_ref, idx_ref, tgt, out_size, A, 
            "tolerance_px": 1e-3, "crop_bytes_differing": differing, "crop_bytes_compared": int(got.size),
            "checker": "oracle/retinaface_ref.predict + oracle/align_ref.crop_align on the first images of the timed batch "
                       "(outputs of the last timed step)"}
-    if not indices_equal or not (err < 1e-3) or differing != 0:
+    rec["vacuous"] = len(idx_l) == 0
+    # zero faces on both sides would "agree" with nothing compared: a regression that suppresses every detection must not pass
+    if len(idx_l) == 0 or int(got.size) == 0 or not indices_equal or not (err < 1e-3) or differing != 0:
         print(json.dumps({"parity_check": rec}), file=sys.stderr, flush=True)
         raise SystemExit("bench.py: the timed batch does not match the oracle (see parity_check on stderr)")
     return rec

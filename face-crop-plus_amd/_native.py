@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_f32p = C.c_void_p
 _lib = None
@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("in_fmt", C.c_int32), ("out_fmt", C.c_int32), ("res1_fmt", C.c_int32), ("res2_fmt", C.c_int32),
         ("tile_m", C.c_int32), ("cin2", C.c_int32), ("in2_ld", C.c_int32), ("in2_h", C.c_int32),
         ("in2_w", C.c_int32), ("in2_stride", C.c_int32), ("flags", C.c_int32), ("cu_budget", C.c_int32),
+        ("band_top", C.c_int32), ("band_bottom", C.c_int32),
     ]
 
 

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
       const int wo = rem - ho * p.out_w;
       nbase[i] = (long)ni * p.ph * p.pw;
       pbase[i] = (unsigned)(ni * p.ph * p.pw);
-      hi0[i] = ho * p.stride - p.pad;
+      hi0[i] = ho * p.stride - p.pad_h;
       wi0[i] = wo * p.stride - p.pad;
     } else {
       nbase[i] = 0;
@@ -294,7 +294,10 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   } else {
     FCP_REQUIRE(d->cin % 32 == 0 && d->cin > 0, "conv: cin must be a multiple of 32 (got %d)", d->cin);
   }
-  const int eh = (d->in_h + 2 * d->pad - d->kh) / d->stride + 1;
+  FCP_REQUIRE(d->band_top >= 0 && d->band_bottom >= 0 && d->band_top <= d->pad && d->band_bottom <= d->pad &&
+              ((d->band_top | d->band_bottom) == 0 || (d->stride == 1 && !d->in2)),
+              "conv: band_top / band_bottom must lie in 0..pad (stride-1 convs without a second source only)");
+  const int eh = (d->in_h - d->band_top - d->band_bottom + 2 * d->pad - d->kh) / d->stride + 1;
   const int ew = (d->in_w + 2 * d->pad - d->kw) / d->stride + 1;
   FCP_REQUIRE(eh == d->out_h && ew == d->out_w, "conv: output size %dx%d does not match geometry %dx%d",
               d->out_h, d->out_w, eh, ew);
@@ -308,7 +311,7 @@ extern "C" int fcp_conv2d_nhwc_f32(const fcp_conv_desc* d, fcp_stream_t stream) 
   k.ph = d->in_up2 ? d->in_h / 2 : d->in_h;
   k.pw = d->in_up2 ? d->in_w / 2 : d->in_w;
   k.cin = d->cin; k.in_ld = d->in_ld; k.in_up2 = d->in_up2;
-  k.cout = d->cout; k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad;
+  k.cout = d->cout; k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad; k.pad_h = d->pad - d->band_top;
   k.out_h = d->out_h; k.out_w = d->out_w; k.out_ld = d->out_ld;
   k.M = (int)M;
   if (d->cin4) {

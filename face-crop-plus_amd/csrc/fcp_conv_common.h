@@ -29,6 +29,7 @@ struct ConvK {
   const float* res2;
   int n, in_h, in_w, ph, pw, cin, in_ld, in_up2;
   int cout, kh, kw, stride, pad, out_h, out_w, out_ld;
+  int pad_h;      // rows of zero padding above input row 0 (= pad - band_top: fcp_conv_desc.band_top / band_bottom)
   int M, ktiles, ctiles, wrow;
   float act_slope, alpha, alpha2;
   int res1_pre, res1_ld, res1_h, res1_w, res1_resize, res2_ld;

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256, (BN == 128 ? 2 : (BN == 64 ? 3 : 4))) con
       const int ho = rem / p.out_w;
       const int wo = rem - ho * p.out_w;
       pbase[i] = (unsigned)(ni * p.ph * p.pw);
-      hi0[i] = ho * p.stride - p.pad;
+      hi0[i] = ho * p.stride - p.pad_h;
       wi0[i] = wo * p.stride - p.pad;
     } else {
       pbase[i] = 0;

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(NT, 1) conv_igemm_f16x3_big(const ConvK p) {
       const int ho = rem / p.out_w;
       const int wo = rem - ho * p.out_w;
       pbase = (unsigned)(ni * p.ph * p.pw);
-      hi0 = ho * p.stride - p.pad;
+      hi0 = ho * p.stride - p.pad_h;
       wi0 = wo * p.stride - p.pad;
       if (p.in2 != nullptr)
         base2[i] = (((unsigned)(ni * p.ph2 + ho * p.stride2) * (unsigned)p.pw2 + (unsigned)(wo * p.stride2)) * (unsigned)p.in2_ld +

@@ -123,10 +123,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_f16x3(const ConvK p) {
       const int ty = (tile / tiles_x) % tiles_y;
       const int ni = tile / (tiles_x * tiles_y);
       const int y0 = ty * TH, x0 = tx * TW;
-      // halo row (hy, hx) -> input pixel (y0 - 1 + hy, x0 - 1 + hx)
+      // halo row (hy, hx) -> input pixel (y0 - pad_h + hy, x0 - 1 + hx); pad_h = 1, or 0 when the input view holds a
+      // real row above the output view (fcp_conv_desc.band_top)
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
-        const int y = y0 - 1 + (hyx[i] >> 8), x = x0 - 1 + (hyx[i] & 255);
+        const int y = y0 - p.pad_h + (hyx[i] >> 8), x = x0 - 1 + (hyx[i] & 255);
         const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)p.in_h && (unsigned)x < (unsigned)p.in_w;
         // in_up2: the logical input is the nearest x2 of the physical one (RRDB's upconv1 / upconv2): the halo row of logical
         // pixel (y, x) is physical pixel (y / 2, x / 2); p.ph / p.pw are the physical sizes (= in_h / in_w otherwise)
@@ -500,7 +501,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_halo_wide_f16x3(const ConvK p)
       const int y0 = ty * TH, x0 = tx * TW;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
-        const int y = y0 - 1 + (hyx[i] >> 8), x = x0 - 1 + (hyx[i] & 255);
+        const int y = y0 - p.pad_h + (hyx[i] >> 8), x = x0 - 1 + (hyx[i] & 255);
         const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)p.in_h && (unsigned)x < (unsigned)p.in_w;
         // in_up2: the logical input is the nearest x2 of the physical one (RRDB's upconv1 / upconv2): the halo row of logical
         // pixel (y, x) is physical pixel (y / 2, x / 2); p.ph / p.pw are the physical sizes (= in_h / in_w otherwise)

@@ -51,14 +51,15 @@ Tensor conv2d_impl(const Tensor& x, int64_t x_c0, int64_t cin, const Tensor& w, 
                    int64_t cout, int64_t kh, int64_t kw, int64_t stride, int64_t pad, double act_slope, double alpha,
                    double alpha2, bool res1_pre, int64_t precision, int64_t in_fmt, int64_t out_fmt, int64_t res1_fmt,
                    int64_t res2_fmt, bool in_up2, bool cin4, int64_t tile_m, int64_t tile_n, const c10::optional<Tensor>& x2,
-                   int64_t x2_c0, int64_t cin2, int64_t x2_stride, int64_t flags, int64_t cu_budget) {
+                   int64_t x2_c0, int64_t cin2, int64_t x2_stride, int64_t flags, int64_t cu_budget, int64_t band_top,
+                   int64_t band_bottom) {
   dev(x, "x", at::kFloat);
   FCP_DEVICE_GUARD(x);
   TORCH_CHECK(x.dim() == 4, "x must be NHWC (n, h, w, ld)");
   TORCH_CHECK(w.is_cuda() && w.is_contiguous(), "w must be a contiguous GPU tensor (packed filter)");
   const int64_t n = x.size(0), ph = x.size(1), pw = x.size(2), ld = x.size(3);
   const int64_t ih = in_up2 ? 2 * ph : ph, iw = in_up2 ? 2 * pw : pw;
-  const int64_t oh = (ih + 2 * pad - kh) / stride + 1, ow = (iw + 2 * pad - kw) / stride + 1;
+  const int64_t oh = (ih - band_top - band_bottom + 2 * pad - kh) / stride + 1, ow = (iw + 2 * pad - kw) / stride + 1;
   Tensor out = out_.has_value() && out_->defined() ? *out_ : at::empty({n, oh, ow, cout}, x.options());
   dev(out, "out", at::kFloat);
   TORCH_CHECK(out.dim() == 4 && out.size(0) == n && out.size(1) == oh && out.size(2) == ow && out_c0 + cout <= out.size(3),
@@ -95,6 +96,7 @@ Tensor conv2d_impl(const Tensor& x, int64_t x_c0, int64_t cin, const Tensor& w, 
   }
   d.flags = (int)flags;
   d.cu_budget = (int)cu_budget;
+  d.band_top = (int)band_top; d.band_bottom = (int)band_bottom;
   ok(fcp_conv2d_nhwc_f32(&d, cur_stream()), "fcp::conv2d");
   return out;
 }
@@ -106,10 +108,11 @@ Tensor conv2d(const Tensor& x, int64_t x_c0, int64_t cin, const Tensor& w, const
               const c10::optional<Tensor>& res2, int64_t res2_c0, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
               int64_t pad, double act_slope, double alpha, double alpha2, bool res1_pre, int64_t precision, int64_t in_fmt,
               int64_t out_fmt, int64_t res1_fmt, int64_t res2_fmt, bool in_up2, bool cin4, int64_t tile_m, int64_t tile_n,
-              const c10::optional<Tensor>& x2, int64_t x2_c0, int64_t cin2, int64_t x2_stride, int64_t flags, int64_t cu_budget) {
+              const c10::optional<Tensor>& x2, int64_t x2_c0, int64_t cin2, int64_t x2_stride, int64_t flags, int64_t cu_budget,
+              int64_t band_top, int64_t band_bottom) {
   return conv2d_impl(x, x_c0, cin, w, bias, wscale, res1, res1_c0, res2, res2_c0, c10::nullopt, 0, cout, kh, kw, stride, pad,
                      act_slope, alpha, alpha2, res1_pre, precision, in_fmt, out_fmt, res1_fmt, res2_fmt, in_up2, cin4, tile_m,
-                     tile_n, x2, x2_c0, cin2, x2_stride, flags, cu_budget);
+                     tile_n, x2, x2_c0, cin2, x2_stride, flags, cu_budget, band_top, band_bottom);
 }
 
 void conv2d_out(const Tensor& x, int64_t x_c0, int64_t cin, const Tensor& w, const c10::optional<Tensor>& bias,
@@ -118,10 +121,10 @@ void conv2d_out(const Tensor& x, int64_t x_c0, int64_t cin, const Tensor& w, con
                 int64_t kw, int64_t stride, int64_t pad, double act_slope, double alpha, double alpha2, bool res1_pre,
                 int64_t precision, int64_t in_fmt, int64_t out_fmt, int64_t res1_fmt, int64_t res2_fmt, bool in_up2, bool cin4,
                 int64_t tile_m, int64_t tile_n, const c10::optional<Tensor>& x2, int64_t x2_c0, int64_t cin2,
-                int64_t x2_stride, int64_t flags, int64_t cu_budget) {
+                int64_t x2_stride, int64_t flags, int64_t cu_budget, int64_t band_top, int64_t band_bottom) {
   conv2d_impl(x, x_c0, cin, w, bias, wscale, res1, res1_c0, res2, res2_c0, out, out_c0, cout, kh, kw, stride, pad, act_slope,
               alpha, alpha2, res1_pre, precision, in_fmt, out_fmt, res1_fmt, res2_fmt, in_up2, cin4, tile_m, tile_n, x2, x2_c0,
-              cin2, x2_stride, flags, cu_budget);
+              cin2, x2_stride, flags, cu_budget, band_top, band_bottom);
 }
 
 std::tuple<Tensor, Tensor> bottleneck_chain(const Tensor& t1, int64_t t1_c0, const c10::optional<Tensor>& res, int64_t res_c0,
@@ -289,11 +292,13 @@ TORCH_LIBRARY(fcp, m) {
   m.def("conv2d(Tensor x, int x_c0, int cin, Tensor w, Tensor? bias, Tensor? wscale, Tensor? res1, int res1_c0, Tensor? res2, "
         "int res2_c0, int cout, int kh, int kw, int stride, int pad, float act_slope, float alpha, "
         "float alpha2, bool res1_pre, int precision, int in_fmt, int out_fmt, int res1_fmt, int res2_fmt, bool in_up2, "
-        "bool cin4, int tile_m, int tile_n, Tensor? x2, int x2_c0, int cin2, int x2_stride, int flags, int cu_budget=0) -> Tensor");
+        "bool cin4, int tile_m, int tile_n, Tensor? x2, int x2_c0, int cin2, int x2_stride, int flags, int cu_budget=0, int band_top=0, "
+        "int band_bottom=0) -> Tensor");
   m.def("conv2d_out(Tensor x, int x_c0, int cin, Tensor w, Tensor? bias, Tensor? wscale, Tensor? res1, int res1_c0, Tensor? res2, "
         "int res2_c0, Tensor(a!) out, int out_c0, int cout, int kh, int kw, int stride, int pad, float act_slope, float alpha, "
         "float alpha2, bool res1_pre, int precision, int in_fmt, int out_fmt, int res1_fmt, int res2_fmt, bool in_up2, "
-        "bool cin4, int tile_m, int tile_n, Tensor? x2, int x2_c0, int cin2, int x2_stride, int flags, int cu_budget=0) -> ()");
+        "bool cin4, int tile_m, int tile_n, Tensor? x2, int x2_c0, int cin2, int x2_stride, int flags, int cu_budget=0, int band_top=0, "
+        "int band_bottom=0) -> ()");
   m.def("bottleneck_chain(Tensor t1, int t1_c0, Tensor? res, int res_c0, Tensor? w2, Tensor? ws2, Tensor? b2, Tensor w3, Tensor ws3, "
         "Tensor b3, Tensor w1n, Tensor ws1n, Tensor b1n, int c, int nout, int cn, int tile_m=0, int flags=0) -> (Tensor, Tensor)");
   m.def("retina_decode(Tensor head0, Tensor head1, Tensor head2, int img_h, int img_w, float vis, float var0, float var1) "

@@ -237,6 +237,8 @@ class Autotune:
     winner; every candidate of the fp16x3 path returns bit-identical tensors, so the choice never changes a
     result.  On by default (env FCP_AUTOTUNE=0 turns it off); a shape tuned once keeps its tile afterwards."""
     enabled = os.environ.get("FCP_AUTOTUNE", "1") != "0"
+    # FCP_AUTOTUNE=0 (bench --no-autotune) means the heuristic tiles: the shipped / user tables are not consulted either
+    use_tables = os.environ.get("FCP_AUTOTUNE", "1") != "0"
     cache: dict = {}
     _lock = threading.Lock()     # process_dir's GPU workers share the cache: one tuner at a time
     # Picks persist on disk, keyed by (ISA name, CU count, ABI version) + shape: a second start skips the timing
@@ -244,6 +246,9 @@ class Autotune:
     # tools/dump_autotune.py), then the user's file ($FCP_TUNE_CACHE, default ~/.cache/face_crop_plus_amd/autotune.json;
     # "0" = no disk cache at all), which also receives every new pick.  Every candidate returns the same bits, so a
     # stale pick can only cost speed; one that is no longer among a shape's candidates is ignored.
+    # Version of the tile vocabulary the tables are keyed by (the ABI version at which the candidate set last changed its
+    # meaning; an ABI bump that only adds descriptor fields keeps the tables valid)
+    TABLE_VERSION = 13
     _disk_loaded = False
     _disk_section = None         # "<device name>|<CUs>|abi<N>"
     _disk_dirty = False
@@ -262,13 +267,13 @@ class Autotune:
             # the marketing name differs between boxes of one pool ("AMD Radeon Graphics" / "AMD Instinct MI355X"):
             # the ISA name + CU count identify the part
             arch = getattr(prop, "gcnArchName", prop.name).split(":")[0]
-            cls._disk_section = f"{arch}|{prop.multi_processor_count}|abi{N.ABI_VERSION}"
+            cls._disk_section = f"{arch}|{prop.multi_processor_count}|abi{cls.TABLE_VERSION}"
         return cls._disk_section
 
     @classmethod
     def ensure_loaded(cls):
         """Merge the shipped and the user's tables into ``cache`` (once per process; in-process picks win)."""
-        if cls._disk_loaded:
+        if cls._disk_loaded or not cls.use_tables:
             return
         with cls._lock:
             if cls._disk_loaded:
@@ -311,7 +316,7 @@ class Autotune:
             except Exception:
                 pass
             sec = table.setdefault(cls.section(), {})
-            for k, v in cls.cache.items():
+            for k, v in list(cls.cache.items()):
                 sec[repr(k)] = list(v)
             os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
             tmp = f"{path}.{os.getpid()}.tmp"
@@ -357,7 +362,7 @@ class Autotune:
         if os.environ.get("FCP_TUNE_CACHE") != "0":
             try:
                 cls.save()
-            except OSError:                                  # read-only home, full disk: tuning still works in-process
+            except Exception:                                # read-only home, full disk, a damaged file: tuning still works in-process
                 pass
         return best
 
@@ -446,16 +451,19 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
          alpha: float = 1.0, res1: Act | None = None, res1_pre: bool = True,
          res2: Act | None = None, alpha2: float = 1.0, in_up2: bool = False,
          tile_n: int | None = None, out_fmt: int = 0, tile_m: int | None = None,
-         x2: Act | None = None, x2_stride: int = 1, flat: bool = False, balance_tail: bool = False) -> Act:
+         x2: Act | None = None, x2_stride: int = 1, flat: bool = False, balance_tail: bool = False,
+         band: tuple[int, int] = (0, 0)) -> Act:
     """Launch one fused convolution.  ``act_slope``: 1 = identity, 0 = ReLU.  ``out_fmt`` selects the
     format of a freshly allocated output (an explicit ``out`` view carries its own).  ``x2``: second
     source of a 1x1 conv — the filter's trailing ``x2.c`` input channels read ``x2`` at
     ``(ho*x2_stride, wo*x2_stride)`` (both sources split32, fp16x3 path).  ``flat``: force the 64-bit
     flat-addressing variant of the fp32 kernel (what tensors >= 4 GiB take on their own).  ``balance_tail`` (with an
-    explicit ``tile_m=256``): the balanced M-tile schedule of the 256-row kernel (the autotuner picks it by itself)."""
+    explicit ``tile_m=256``): the balanced M-tile schedule of the 256-row kernel (the autotuner picks it by itself).
+    ``band`` = (rows above, rows below): real rows the input view holds around the rows the output view covers, in place of the
+    zero padding at the view's edge (``fcp_conv_desc.band_top / band_bottom``): rows [a, b) of a larger image's conv, exactly."""
     assert x.c + (x2.c if x2 is not None else 0) == pc.cin, f"conv expects {pc.cin} input channels, got {x.c}"
     in_h, in_w = (x.h * 2, x.w * 2) if in_up2 else (x.h, x.w)
-    oh = (in_h + 2 * pc.pad - pc.kh) // pc.stride + 1
+    oh = (in_h - band[0] - band[1] + 2 * pc.pad - pc.kh) // pc.stride + 1
     ow = (in_w + 2 * pc.pad - pc.kw) // pc.stride + 1
     if out is None:
         out = Act.empty(x.n, oh, ow, pc.cout, x.buf.device, out_fmt)
@@ -487,6 +495,7 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     d.res1_pre = int(res1_pre)
     d.flags = (N.CONV_FLAT_ADDR if flat else 0) | (N.CONV_BALANCE_TAIL if balance_tail else 0)
     d.cu_budget = getattr(_budget, "cus", 0)
+    d.band_top, d.band_bottom = band
     if res1 is not None:
         assert res1.c == pc.cout and res1.n == x.n
         d.res1_ld, d.res1_h, d.res1_w = res1.ld, res1.h, res1.w
@@ -518,7 +527,8 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
                 cands += [(tm, tn, N.CONV_BALANCE_TAIL) for tm, tn in big]
         best = Autotune.cache.get(key)          # a tuned shape keeps its tile after tuning is switched off
         if best is not None and tuple(best) not in cands:
-            Autotune.cache.pop(key, None)       # a pick from an older table that this build no longer offers
+            with Autotune._lock:                # (save() walks the cache under the same lock in another GPU worker thread)
+                Autotune.cache.pop(key, None)   # a pick from an older table that this build no longer offers
             best = None
         if best is None and Autotune.enabled:
             # Tuning launches the op several times.  An op whose output aliases one of its inputs (RRDB's last dense-block
@@ -557,7 +567,7 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
                             out.buf, out.c0, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad, float(act_slope), float(alpha), float(alpha2),
                             bool(res1_pre), pc.precision, x.fmt, out.fmt, d.res1_fmt, d.res2_fmt, bool(in_up2), bool(pc.cin4),
                             int(d.tile_m), int(d.tile_n), None if x2 is None else x2.buf, 0 if x2 is None else x2.c0,
-                            0 if x2 is None else x2.c, int(x2_stride), int(d.flags), int(d.cu_budget))
+                            0 if x2 is None else x2.c, int(x2_stride), int(d.flags), int(d.cu_budget), int(band[0]), int(band[1]))
     else:
         N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
     if timing is not None:

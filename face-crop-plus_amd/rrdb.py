@@ -96,12 +96,16 @@ class RRDBNet:
         bufs = [E.Act.empty(n, h, w, 192, dev, f) for _ in range(3)]  # one dense-block concat buffer per RDB
         fea0 = E.conv(p["conv_first"], x4, out_fmt=f)                  # kept for the trunk residual
         E.conv(p["conv_first"], x4, bufs[0].slice(0, 64))              # and as x of the first RDB
+        band = self.TRUNK_BAND if 0 < self.TRUNK_BAND < h else 0
         for t, rrdb in enumerate(p["trunk"]):
             for r, convs in enumerate(rrdb):
-                b = bufs[r]
+                b, nxt = bufs[r], bufs[(r + 1) % 3]
+                x_rrdb = bufs[0] if r == 2 else None                   # RDB3 also applies the RRDB's own residual
+                if band:
+                    self._dense_block_banded(convs, b, nxt, x_rrdb, band)
+                    continue
                 for c in range(4):                                     # x_{c+1} = lrelu(conv(cat(x..x_c)))
                     E.conv(convs[c], b.slice(0, 64 + 32 * c), b.slice(64 + 32 * c, 32), act_slope=0.2)
-                nxt = bufs[(r + 1) % 3]
                 if r < 2:                                              # x5*0.2 + x -> next RDB's x
                     E.conv(convs[4], b, nxt.slice(0, 64), alpha=0.2, res1=b.slice(0, 64), res1_pre=False)
                 else:                                                  # (x5*0.2 + x)*0.2 + x_rrdb
@@ -111,6 +115,39 @@ class RRDBNet:
         del bufs
         fea = E.conv(p["upconv1"], fea, act_slope=0.2, in_up2=True, out_fmt=f)
         return self._tail(fea, f)
+
+    # Rows per band of the band-major dense-block schedule (0 = every conv over the whole image).
+    TRUNK_BAND = int(os.environ.get("FCP_RRDB_BAND", "0"))
+
+    @staticmethod
+    def _dense_block_banded(convs, b: E.Act, nxt: E.Act, x_rrdb: E.Act | None, band: int):
+        """One residual dense block (_layers.py:168-200 of the reference) band-major: conv1 .. conv5 on one band of rows
+        before the next band, so that the block's growing concat (192 channels x 4 B x W x band: 108 MB for 128 rows of a
+        1024-wide image) is re-read from the memory-side cache instead of from HBM (whole-image launches re-read 20 channel
+        slices of 268 MB per block).  Rows [r0, r1) of conv5 need rows [r0 - m, r1 + m) of conv(5 - m): each conv computes
+        exactly those rows of the whole-image convolution from an input view that holds one real row above and below
+        (``band`` of ``engine.conv``; at the image's edges the view ends there and the zero padding is the right one).  The
+        4 + 3 + 2 + 1 margin rows per side are computed twice (+3 % of the block's work at 128 rows) and give the same
+        values both times: bit-identical to the whole-image schedule (tests/test_parse_enhance_gpu.py)."""
+        n, h = b.n, b.h
+        rows = lambda t, i, a, e: E.Act(t.buf[i:i + 1, a:e], t.c0, t.c, t.fmt)
+        for i in range(n):
+            for r0 in range(0, h, band):
+                r1 = min(h, r0 + band)
+                for c in range(5):
+                    m = 4 - c
+                    oa, ob = max(0, r0 - m), min(h, r1 + m)             # output rows of this conv
+                    ia, ib = max(0, oa - 1), min(h, ob + 1)             # input rows it reads
+                    bd = (oa - ia, ib - ob)
+                    x = rows(b.slice(0, 64 + 32 * c), i, ia, ib)
+                    if c < 4:
+                        E.conv(convs[c], x, rows(b.slice(64 + 32 * c, 32), i, oa, ob), act_slope=0.2, band=bd)
+                    elif x_rrdb is None:
+                        E.conv(convs[4], x, rows(nxt.slice(0, 64), i, oa, ob), alpha=0.2, res1=rows(b.slice(0, 64), i, oa, ob),
+                               res1_pre=False, band=bd)
+                    else:
+                        E.conv(convs[4], x, rows(nxt.slice(0, 64), i, oa, ob), alpha=0.2, res1=rows(b.slice(0, 64), i, oa, ob),
+                               res1_pre=False, res2=rows(x_rrdb.slice(0, 64), i, oa, ob), alpha2=0.2, band=bd)
 
     TAIL_BAND = int(os.environ.get("FCP_RRDB_TAIL_BAND", "256"))    # x4-resolution output rows per band
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 13
+#define FCP_ABI_VERSION 14
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -118,6 +118,15 @@ typedef struct fcp_conv_desc {
    * CUs the launch may count on (0 = all of the device; a caller that runs two such launches concurrently on two
    * streams passes half).  Neither changes a result. */
   int32_t cu_budget;
+  /* Row bands (stride 1): the input view holds band_top real rows above and band_bottom real rows below the rows the
+   * output view covers (0 <= each <= pad), instead of the zero padding a conv applies at the edge of its view:
+   *     out_h = in_h - band_top - band_bottom + 2 pad - kh + 1,    input row of (output row ho, tap kh_i) = ho - pad + band_top + kh_i.
+   * This is how a caller computes rows [a, b) of a larger image's convolution exactly: `in` = rows [a - band_top, b + band_bottom)
+   * with band_top = 0 only at the image's top edge (where the zero padding is the right one).  RRDB's dense blocks run
+   * band-major this way (rrdb.py: conv1..conv5 of a block on one row band before the next band, the growing concat
+   * staying in the memory-side cache; _layers.py:168-200 of the reference).  Same arithmetic per output pixel: bit-identical to
+   * the whole-image launch.  Both 0: the ordinary convolution. */
+  int32_t band_top, band_bottom;
 } fcp_conv_desc;
 
 #define FCP_CONV_FLAT_ADDR 1

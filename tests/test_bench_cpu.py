@@ -48,3 +48,66 @@ def test_parity_checker_accepts_the_oracle_and_rejects_a_shifted_landmark(monkey
             bad = (last[0], torch.from_numpy(c2), last[2])
         with pytest.raises(SystemExit, match="does not match the oracle"):
             bench.check_against_oracle(bad, images, k, lm_ref, idx_ref, tgt, out, A)
+
+
+def test_parity_checker_rejects_a_vacuous_pass():
+    """Zero faces on both sides (a regression that suppresses every detection in the oracle AND on the GPU) must not count as
+    parity: nothing was compared."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import align_ref as A
+    out = 32
+    images = torch.zeros((2, 64, 64, 3), dtype=torch.uint8)
+    tgt = A.landmarks_target((out, out), 0.65)
+    last = ({"face_offset": torch.tensor([0, 0, 0]), "img_idx": torch.zeros(4, dtype=torch.int32), "landmarks": torch.zeros(4, 5, 2)},
+            torch.zeros((4, out, out, 3), dtype=torch.uint8), torch.zeros(4, dtype=torch.int32))
+    with pytest.raises(SystemExit, match="does not match the oracle"):
+        bench.check_against_oracle(last, images, 2, np.zeros((0, 5, 2), np.float32), [], tgt, out, A)
+
+
+def test_eight_gpu_preflight_self_launch_and_guards(monkeypatch):
+    """Pre-flight for the 8-GPU node (no such node in any round so far): `python bench.py --gpus 8` re-executes itself as
+    eight ranks under torch.distributed.run on 127.0.0.1 with dmabuf IPC kept in the environment, and every mismatch between
+    --gpus, WORLD_SIZE and the visible devices stops the run before any rank could silently measure the wrong thing."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = list(cmd), dict(env)
+        return 0
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    with pytest.raises(SystemExit) as ei:
+        bench.self_launch(8)
+    assert ei.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 <= int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]        # the ranks get the caller's own flags
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"                       # RCCL needs dmabuf IPC on this driver
+    # fewer devices than ranks: refused by the launcher path ...
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    with pytest.raises(SystemExit, match="only 4 GPU"):
+        bench.self_launch(8)
+    # ... and by a rank that a foreign launcher started (WORLD_SIZE = 8 on a 4-GPU box), before it touches a device
+    for k, v in (("WORLD_SIZE", "8"), ("RANK", "5"), ("LOCAL_RANK", "5")):
+        monkeypatch.setenv(k, v)
+    with pytest.raises(SystemExit, match="only 4 GPU"):
+        bench.main()
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit, match="WORLD_SIZE=2"):
+        bench.main()
+
+
+def test_cpu_baseline_host_description():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert isinstance(bench.cpu_model(), str) and bench.cpu_model()
+    assert 1 <= bench.host_cores() <= (os.cpu_count() or 1)

@@ -422,6 +422,44 @@ def test_conv_halo_wide_tiles(cin, cout, hw, n, device, precision):
                E.f32_to_split32(E.Act(_nhwc(torch.randn(1, 96, 8, 8), device))), tile_m=1, tile_n=tn)
 
 
+@pytest.mark.parametrize("cin,cout,hw,tiles", [
+    (64, 32, (40, 70), [(128, 32), (1, 32)]),                     # halo kernel, one pass
+    (192, 64, (37, 45), [(128, 64), (1, 32), (1, 64)]),           # halo kernel two passes, wide halo (64 filters, residuals)
+    (128, 128, (33, 64), [(128, 128), (128, 64), (1, 128), (256, 128)]),   # wide halo, 256-row kernel
+    (64, 256, (70, 40), [(128, 128), (256, 256)]),
+])
+def test_conv_row_bands(cin, cout, hw, tiles, device, precision):
+    """``band`` (fcp_conv_desc.band_top / band_bottom): rows [a, b) of a 3x3 conv computed from the row view [a - 1, b + 1) of
+    its input (one real row above / below instead of the zero padding at the view's edge; at the image's edges the view ends
+    there) are the bits of the whole-image launch, for every kernel family, with residual views of the same rows."""
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(cin + cout)
+    h, w = hw
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(1, cout, h, w, generator=g)
+    pc = E.pack_conv(wt, b, None, 1, 1, device)
+    xa, ra = E.Act(_nhwc(x, device)), E.Act(_nhwc(res, device))
+    split = precision == "f16x3"
+    if split:
+        xa = E.f32_to_split32(xa)
+    rows = lambda t, a, e: E.Act(t.buf[:, a:e], t.c0, t.c, t.fmt)
+    for tm, tn in (tiles if split else [(128, 64)]):
+        with_res = not (tm == 1 and tn == 128)                     # the wide halo kernel takes no residual above 64 filters
+        kw = dict(act_slope=0.2, alpha=0.5, tile_m=tm, tile_n=tn, out_fmt=int(split and cout % 32 == 0))
+        whole = E.conv(pc, xa, res1=ra if with_res else None, res1_pre=False, **kw)
+        got = E.Act.empty(1, h, w, cout, device, whole.fmt)
+        got.buf.fill_(float("nan"))
+        for a, e in ((0, 9), (9, 10), (10, 27), (27, h)):          # bands of 9, 1, 17 and the rest
+            ia, ib = max(0, a - 1), min(h, e + 1)
+            E.conv(pc, rows(xa, ia, ib), rows(got, a, e), res1=rows(ra, a, e) if with_res else None, res1_pre=False,
+                   band=(a - ia, ib - e), **kw)
+        assert torch.equal(got.buf, whole.buf), (tm, tn)
+    with pytest.raises(RuntimeError, match="band_top"):
+        E.conv(pc, rows(xa, 0, 12), band=(2, 0))
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 77, 91), (1, 64, 64), (3, 50, 130), (1, 9, 200), (2, 640, 640)])
 def test_fused_stem_pool(n, h, w, device, precision):
     """uint8 -> (x - mean) -> 7x7/2 conv + BN + ReLU -> max-pool 3x3/2 in one launch (RetinaFace stem, fp16x3 path):

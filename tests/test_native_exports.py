@@ -38,7 +38,7 @@ def test_conv_desc_layout_matches_header():
         fields += [n.strip().lstrip("*") for n in names.split(",")]
     mine = [f[0].rstrip("_") for f in N.ConvDesc._fields_]
     assert fields == mine
-    assert ctypes.sizeof(N.ConvDesc) == 8 * 8 + 38 * 4      # 8 pointers + 37 int32 / float fields (+ 4 bytes of tail padding)
+    assert ctypes.sizeof(N.ConvDesc) == 8 * 8 + 40 * 4      # 8 pointers + 39 int32 / float fields (+ 4 bytes of tail padding)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
