@@ -253,6 +253,22 @@ class IOProcesses:
         self._free_r, self._free_w = list(self._readers), list(self._writers)
         self._tls = threading.local()
 
+    def healthy(self) -> bool:
+        """Whether the pool can serve another run: every worker process is alive and no ring region of an earlier run is still
+        outstanding.  A run that failed half-way (a worker OOM-killed, an error reply in the middle of a request, prefetched
+        batches that were read but never collected) leaves dead processes or regions nobody will give back — such a pool is
+        closed and replaced by its owner (``Cropper._io_processes``), never reused: a leaked region would push that decoder to
+        the socket path for good, a dead one would fail every later run."""
+        if self.closed:
+            return False
+        for w in self._readers + self._writers:
+            if w.proc.poll() is not None:
+                return False
+            with w.lock:
+                if w.regions:
+                    return False
+        return True
+
     def _mine(self, name, free):
         w = getattr(self._tls, name, None)
         if w is None:

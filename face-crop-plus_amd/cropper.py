@@ -421,6 +421,7 @@ class Cropper:
                 if procs is not None:
                     procs.release(tokens)
 
+        failed = True
         try:
             with ThreadPool(self.num_processes) as pool:
                 imap = pool.imap(worker, range(len(file_batches)))
@@ -433,12 +434,20 @@ class Cropper:
                 list(imap)
             for w in writes:
                 w.result()                       # surface encode / write errors
+            failed = False
         finally:
             io.shutdown(wait=True)       # in-flight tasks still hold the semaphore / list: reset only afterwards
             if wio is not io:
                 wio.shutdown(wait=True)
             self._io = None
             self._io_procs_active = None
+            # A run that failed may have left a dead worker, a request cut off in the middle (its ring space handed out but
+            # never reported) or prefetched batches nobody collected: that pool is not reused — the next run starts fresh
+            # workers instead of inheriting the damage.
+            if procs is not None and (failed or not procs.healthy()):
+                procs.close()
+                if self._io_procs is procs:
+                    self._io_procs = None
 
     @staticmethod
     def _pin_ring(ring, nbytes) -> bool:
@@ -470,7 +479,7 @@ class Cropper:
         if min(want) <= 0:
             return None
         have = self._io_procs
-        if have is not None and not have.closed and (have.readers, have.writers) == tuple(want):
+        if have is not None and have.healthy() and (have.readers, have.writers) == tuple(want):
             return have
         if have is not None:
             have.close()

@@ -290,3 +290,42 @@ def test_process_dir_without_detector_copies_borrowed_images(tmp_path, device):
     assert len(outs["threads"]) == 24 and outs["threads"] == outs["procs"]
     for f, b in outs["procs"].items():                          # and they ARE the inputs (PNG is lossless)
         assert np.array_equal(np.asarray(Image.open(tmp_path / "procs" / f)), np.asarray(Image.open(src / f)))
+
+
+def test_process_dir_recovers_after_a_decode_worker_dies(image_dir, tmp_path, device):
+    """A run whose I/O worker process dies fails loudly — and the NEXT run on the same Cropper starts fresh workers instead of
+    getting the dead process (or ring regions the aborted run never gave back) again; its output is the synchronous run's."""
+    import warnings
+    from face_crop_plus_amd import Cropper, weights
+    sd = weights.generate_state_dict("retinaface")
+    mk = lambda: Cropper(output_size=64, resize_size=160, strategy="largest", det_threshold=0.6, batch_size=2, output_format="png",
+                         device="cuda:0", weights={"retinaface": sd})
+    c = mk()
+    c.io_processes = (2, 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c.process_dir(image_dir, str(tmp_path / "first"), desc=None)
+        pool = c._io_procs
+        assert pool is not None and pool.healthy()
+        for w in pool._readers:                                  # every decoder gone: the next run cannot succeed with this pool
+            w.proc.kill()
+            w.proc.wait(timeout=5)
+        c.process_dir(image_dir, str(tmp_path / "second"), desc=None)      # unhealthy pool replaced up front
+        assert c._io_procs is not pool and pool.closed and c._io_procs.healthy()
+        # a death DURING a run: the run raises, the pool is dropped, the run after it works
+        pool2 = c._io_procs
+        real = pool2.read_many
+
+        def dying(paths):
+            for w in pool2._readers:
+                w.proc.kill()
+            return real(paths)
+        pool2.read_many = dying
+        with pytest.raises(RuntimeError, match="I/O worker process"):
+            c.process_dir(image_dir, str(tmp_path / "broken"), desc=None)
+        assert c._io_procs is None and pool2.closed
+        c.process_dir(image_dir, str(tmp_path / "third"), desc=None)
+    ref = sorted(os.listdir(tmp_path / "first"))
+    assert ref and sorted(os.listdir(tmp_path / "second")) == ref and sorted(os.listdir(tmp_path / "third")) == ref
+    for f in ref:
+        assert (tmp_path / "first" / f).read_bytes() == (tmp_path / "third" / f).read_bytes()

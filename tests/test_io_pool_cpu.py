@@ -130,3 +130,25 @@ def test_workers_exit_when_the_parent_dies_without_closing(tmp_path):
         alive = [pid for pid in alive if os.path.exists(f"/proc/{pid}") and "Z" not in open(f"/proc/{pid}/stat").read().split(")")[1].split()[0]]
         time.sleep(0.1)
     assert not alive, f"worker processes {alive} survived their parent"
+
+
+def test_unhealthy_pool_is_detected(tmp_path):
+    """A pool with a dead worker or with ring regions an aborted run never gave back must not be reused
+    (Cropper._io_processes replaces it): ``healthy()`` is the test."""
+    from PIL import Image
+    from face_crop_plus_amd._io_pool import IOProcesses
+    Image.fromarray(_img(64, 64, 1)).save(tmp_path / "a.png")
+    p = IOProcesses(2, 1, ring_mb=1)
+    try:
+        assert p.healthy()
+        arr, tok = p.read(str(tmp_path / "a.png"))
+        assert tok is not None and not p.healthy()                  # a region is outstanding (a prefetched, uncollected batch)
+        p.release([tok])
+        assert p.healthy()
+        victim = p._writers[0].proc
+        victim.kill()
+        victim.wait(timeout=5)
+        assert not p.healthy()                                      # a dead encoder
+    finally:
+        p.close()
+    assert not p.healthy()                                          # closed
