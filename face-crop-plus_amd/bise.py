@@ -84,6 +84,8 @@ class BiSeNet:
                     ref = twin.forward_logits8(x4)
                     rep["logit_rel_diff"] = E.selfcheck_compare("BiSeNet logits", lg.buf[..., :NUM_CLASSES],
                                                                 ref.buf[..., :NUM_CLASSES], rel_tol)
+                    del twin, ref                                        # the exact-fp32 twin lives for this comparison only
+                    torch.cuda.empty_cache()
             finally:
                 E.Autotune.enabled = tuning
         self.selfcheck_report = rep

@@ -430,12 +430,21 @@ def selfcheck_mode(weights) -> bool:
 
 
 def selfcheck_compare(what: str, got: torch.Tensor, ref: torch.Tensor, rel_tol: float) -> float:
-    """max |got - ref| relative to the reference map's largest value (diagnostic arithmetic, not the data path)."""
+    """max |got - ref| relative to the reference map's largest value (diagnostic arithmetic, not the data path).
+
+    A disagreement above ``rel_tol`` is a WARNING unless FCP_SELFCHECK=1 asked for the strict check: the tolerance was set on
+    this package's generated weights — the release checkpoints have never been through this path (no network in the build
+    container) — and a false positive must not make the default ``Cropper()`` unusable.  The range guard (``RangeMonitor``:
+    |x| >= 2^15 saturates binary16) stays a hard error in every mode: that one is arithmetic, not calibration."""
     scale = float(ref.abs().max().item())
     diff = float((got - ref).abs().max().item()) / max(scale, 1e-30)
     if not diff <= rel_tol:
-        raise FloatingPointError(f"{what}: the fp16x3 path and the exact-fp32 path disagree by {diff:.3g} of the output's "
-                                 f"largest value (tolerance {rel_tol:g}) with these weights; load with precision='f32'.")
+        msg = (f"{what}: the fp16x3 path and the exact-fp32 path disagree by {diff:.3g} of the output's "
+               f"largest value (tolerance {rel_tol:g}) with these weights; load with precision='f32'.")
+        if os.environ.get("FCP_SELFCHECK", "auto") == "1":
+            raise FloatingPointError(msg)
+        import warnings
+        warnings.warn(msg)
     return diff
 
 

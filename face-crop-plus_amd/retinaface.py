@@ -110,6 +110,8 @@ class RetinaFace:
                     ref = twin.forward_heads(E.u8_to_nhwc4(images_u8, sub=(123.0, 117.0, 104.0)))
                     rep["head_rel_diff"] = [E.selfcheck_compare("RetinaFace head maps", a.buf, b.buf, rel_tol)
                                             for a, b in zip(heads, ref)]
+                    del twin, ref                                        # the exact-fp32 twin (a second copy of the filters
+                    torch.cuda.empty_cache()                             # on the device) lives for this comparison only
             finally:
                 E.Autotune.enabled = tuning
         self.selfcheck_report = rep

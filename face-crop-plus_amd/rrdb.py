@@ -81,8 +81,11 @@ class RRDBNet:
                     y = self.forward(x4)
                 rep = {"launch_absmax": mon.check("RRDBNet"), "limit": E.RangeMonitor.LIMIT, "output_rel_diff": None}
                 if sd is not None:
-                    ref = RRDBNet(self.min_face_factor).load(dev, sd, "f32").forward(x4)
+                    twin = RRDBNet(self.min_face_factor).load(dev, sd, "f32")
+                    ref = twin.forward(x4)
                     rep["output_rel_diff"] = E.selfcheck_compare("RRDBNet x4 output", y.buf[..., :3], ref.buf[..., :3], rel_tol)
+                    del twin, ref                                        # the exact-fp32 twin (a second copy of the 351 filters
+                    torch.cuda.empty_cache()                             # on the device) lives for this comparison only
             finally:
                 E.Autotune.enabled = tuning
         self.selfcheck_report = rep

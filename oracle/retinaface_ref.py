@@ -233,3 +233,25 @@ def predict(images, sd, strategy="all", vis=0.6, nms_threshold=0.4, return_all=F
         return lm, indices, dict(scores=scores, boxes=boxes, landms=landms, kept=kept,
                                  fl=fl, fb=fb, sidx=sidx, sel=sel)
     return lm, indices
+
+
+@torch.no_grad()
+def landmarks_fp64(images, sd, ex):
+    """float64 evaluation of the landmarks of the faces ``predict(..., return_all=True)`` selected (``ex`` = its third return
+    value): the network (forward_raw) and decode_landms (retinaface.py:204-210, :455-461) in double precision, on the float32
+    priors the reference uses, for exactly the priors that survived the float32 path's filter / NMS / strategy.  Test
+    infrastructure: the yardstick that says how far the float32 oracle ITSELF is from the exact result, so that a GPU tolerance
+    looser than north_star's 1e-3 px is never needed — |gpu - fp64| <= |oracle - fp64| + 1e-3 is the assertion."""
+    x = preprocess(images).double()
+    sd64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in sd.items()}
+    _, _, ldm = forward_raw(x, sd64)
+    h, w = x.shape[2], x.shape[3]
+    pri = prior_box(h, w).astype(np.float64)
+    flat = [(i, p) for i, kept in enumerate(ex["kept"]) for p in kept]      # filter_preds order: image-major, keep order
+    out = np.zeros((len(ex["sel"]), 5, 2), np.float64)
+    scale = np.array([w, h], np.float64)
+    for r, s in enumerate(ex["sel"]):
+        i, p = flat[s]
+        d = ldm[i, p].numpy().reshape(5, 2)
+        out[r] = (pri[p, :2] + (d * 0.1) * pri[p, 2:]) * scale
+    return out

@@ -37,16 +37,17 @@ def test_process_dir_matches_oracle(image_dir, tmp_path, device):
     imgs, _ = utils.read_images(names, image_dir)
     batch, _, pads = B.as_batch(imgs, (160, 160))           # oracle cv2.resize + pad
     lm, idx = R.predict(torch.from_numpy(batch).permute(0, 3, 1, 2).float(), sd, "largest", 0.6)
-    lm = lm - pads[idx][:, None, [2, 0]]
-    crops = A.crop_align(batch, pads, idx, lm, A.landmarks_target((64, 64), 0.65), (64, 64), "constant")
     assert written == [names[i] for i in idx]
-    worst = 0
+    # landmarks: the detector on the same batch against the oracle, north_star's 1e-3 px; crops: the written files are
+    # byte-equal to the oracle's estimate + warp of the GPU's own landmarks (a landmark difference of 1e-4 px flips isolated
+    # fixed-point roundings between the two landmark sets; this comparison needs no byte budget)
+    lm_g, idx_g = c.det_model.predict(torch.from_numpy(batch).to(c.device))
+    assert list(idx_g) == list(idx) and np.abs(lm_g - lm).max() < 1e-3
+    un = lm_g - pads[idx][:, None, [2, 0]].astype(np.float32)
+    crops = A.crop_align(batch, pads, idx, un, A.landmarks_target((64, 64), 0.65), (64, 64), "constant")
     for k, i in enumerate(idx):
         got = np.asarray(Image.open(out / names[i]).convert("RGB"))
-        worst = max(worst, int(np.abs(got.astype(int) - crops[k].astype(int)).max()))
-        # landmarks agree to ~1e-4 px, so at most isolated fixed-point weight flips may differ
-        assert (got != crops[k]).mean() < 0.01
-    print("worst crop byte difference vs oracle:", worst)
+        assert np.array_equal(got, crops[k]), names[i]
 
 
 def test_process_dir_all_strategy_groups_and_masks(image_dir, tmp_path, device):
@@ -115,7 +116,9 @@ def test_nonsquare_resize_all_strategy_with_parse(tmp_path, device):
     assert batch.shape == (3, 128, 192, 3) and pads[0].tolist() == [10, 10, 0, 0]
     lm, idx = R.predict(torch.from_numpy(batch).permute(0, 3, 1, 2).float(), sd, "all", 0.55)
     assert len(idx) > 3                                             # several faces per image
-    lm = lm - pads[idx][:, None, [2, 0]]
+    lm_g, idx_g = c.det_model.predict(torch.from_numpy(batch).to(c.device))        # the GPU's landmarks on the same batch
+    assert list(idx_g) == list(idx) and np.abs(lm_g - lm).max() < 1e-3            # north_star's tolerance vs the oracle
+    lm = lm_g - pads[idx][:, None, [2, 0]].astype(np.float32)
     crops = A.crop_align(batch, pads, idx, lm, A.landmarks_target((48, 64), 0.65), (48, 64), "constant")
     assert crops.shape[1:] == (64, 48, 3)                           # (h, w) from output_size=(w, h)
     written = sorted(os.listdir(out / "hair"))
@@ -129,7 +132,7 @@ def test_nonsquare_resize_all_strategy_with_parse(tmp_path, device):
         stem, j = fn[:-4].rsplit("_", 1)
         face = k_of[names.index(stem + ".png")][int(j)]
         got = np.asarray(Image.open(out / "hair" / fn).convert("RGB"))
-        assert got.shape == (64, 48, 3) and (got != crops[face]).mean() < 0.01
+        assert got.shape == (64, 48, 3) and np.array_equal(got, crops[face])      # the oracle's warp of the GPU's landmarks, byte for byte
     assert sorted(os.listdir(out / "hair_mask")) == written
 
 

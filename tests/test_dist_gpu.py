@@ -86,13 +86,18 @@ def _rccl_worker(rank, port, out):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     from face_crop_plus_amd import weights
     from face_crop_plus_amd import dist as D
-    sd = weights.generate_state_dict("retinaface")
-    bc = D.broadcast_state_dict(sd, device=torch.device("cuda:0"))
-    same = all(torch.equal(bc[k], sd[k]) for k in sd if not k.endswith("num_batches_tracked"))
+    # the three networks of configs[2] / [3] (what `bench.py --workload full --gpus N` broadcasts; 228.9 MB)
+    same, nbytes = True, 0
+    for name in ("retinaface", "rrdb", "bisenet"):
+        sd = weights.generate_state_dict(name)
+        bc = D.broadcast_state_dict(sd, device=torch.device("cuda:0"))
+        keys = [k for k in sd if not k.endswith("num_batches_tracked")]
+        same = same and all(torch.equal(bc[k], sd[k]) for k in keys)
+        nbytes += sum(4 * sd[k].numel() for k in keys)
     s = D.all_reduce_scalar(41.0, "sum", device=torch.device("cuda:0"))
     m = D.all_reduce_scalar(7.5, "max", device=torch.device("cuda:0"))
     with open(out, "w") as f:
-        f.write(f"{int(same)} {s} {m} {dist.get_backend()}")
+        f.write(f"{int(same)} {s} {m} {dist.get_backend()} {nbytes}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,8 +105,9 @@ def _rccl_worker(rank, port, out):
 def test_rccl_world1_broadcast_and_reduce(tmp_path, device):
     out = tmp_path / "rccl.txt"
     mp.spawn(_rccl_worker, args=(_free_port(), str(out)), nprocs=1, join=True)
-    same, s, m, backend = out.read_text().split()
+    same, s, m, backend, nbytes = out.read_text().split()
     assert same == "1" and float(s) == 41.0 and float(m) == 7.5 and backend == "nccl"
+    assert 220e6 < int(nbytes) < 240e6                          # detector + enhancer + parser, fp32
 
 
 def _cli_worker(rank, world, port, src, out, ckpt):

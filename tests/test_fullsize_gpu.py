@@ -138,7 +138,8 @@ def test_c5_4k_frames_strategy_all(tmp_path, device):
     batch, _, epads = B.as_batch(frames, 1024)
     assert pads.tolist() == epads.tolist() == [[224, 224, 0, 0]] * 2
     assert np.array_equal(dev_batch.cpu().numpy(), batch)
-    lm_ref, idx_ref = R.predict(torch.from_numpy(batch).permute(0, 3, 1, 2).float(), sd, "all", 0.55)
+    x_ref = torch.from_numpy(batch).permute(0, 3, 1, 2).float()
+    lm_ref, idx_ref, ex = R.predict(x_ref, sd, "all", 0.55, return_all=True)
     lm, idx = c.det_model.predict(dev_batch)
     assert list(idx) == list(idx_ref) and len(idx) > 50                     # same faces per image, same order
     # Inside the zero padding the input is translation invariant: whole rows of priors tie (or differ by one ulp
@@ -147,12 +148,21 @@ def test_c5_4k_frames_strategy_all(tmp_path, device):
     on_image = (lm_ref[:, :, 1].max(1) >= 224) & (lm_ref[:, :, 1].min(1) < 800)
     assert on_image.sum() >= 30
     err = np.abs(lm - lm_ref)
-    assert err[on_image].max() < 2e-3, float(err[on_image].max())
-    assert np.abs(lm[..., 1] - lm_ref[..., 1]).max() < 2e-3                 # band faces: same rows
-    un = lm_ref - epads[idx_ref][:, None, [2, 0]]
+    # north_star's 1e-3 px against a float64 evaluation of the same faces (oracle/retinaface_ref.landmarks_fp64): the GPU may be
+    # as far from the exact landmarks as the float32 oracle itself is, plus 1e-3, never more — and within 1e-3 of the oracle
+    l64 = R.landmarks_fp64(x_ref, sd, ex)
+    e_gpu, e_ora = float(np.abs(lm - l64)[on_image].max()), float(np.abs(lm_ref - l64)[on_image].max())
+    print(f"C5 on-image faces: |gpu - fp64| {e_gpu:.3g} px, |oracle - fp64| {e_ora:.3g} px, |gpu - oracle| {float(err[on_image].max()):.3g} px; "
+          f"band faces, rows: {float(np.abs(lm[..., 1] - lm_ref[..., 1]).max()):.3g} px")
+    assert e_gpu <= e_ora + 1e-3 and err[on_image].max() < 1e-3, (e_gpu, e_ora, float(err[on_image].max()))
+    assert np.abs(lm[..., 1] - lm_ref[..., 1]).max() < 1e-3                 # band faces: same rows
+    # crops: byte-equal to the oracle's estimate + warp OF THE GPU'S OWN LANDMARKS (cropper.py:514-547) — the landmark
+    # noise above (1e-4 px) flips isolated fixed-point roundings between the two landmark sets, so comparing against the
+    # warp of the oracle's landmarks would need a byte budget; this comparison needs none
+    un = lm - epads[idx_ref][:, None, [2, 0]].astype(np.float32)
     ref_crops = A.crop_align(batch, epads, idx_ref, un, A.landmarks_target((128, 128), 0.65), (128, 128), "constant")
     got = c.crop_align(batch, pads, list(idx), lm - pads[idx][:, None, [2, 0]].astype(np.float32))
-    assert got.shape == ref_crops.shape and (got[on_image] != ref_crops[on_image]).mean() < 0.02   # 1e-4 px landmark noise flips some fixed-point roundings
+    assert got.shape == ref_crops.shape and np.array_equal(got, ref_crops)
 
 
 def _photo_like(h, w, seed):

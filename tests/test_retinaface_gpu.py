@@ -113,8 +113,15 @@ def test_degenerate_image_sizes_vs_oracle(hw, sd, device):
     g = torch.Generator().manual_seed(h * 100 + w)
     img = torch.randint(0, 256, (2, h, w, 3), generator=g, dtype=torch.uint8)
     lm, idx = RetinaFace("all", 0.5).load(device, sd).predict(img)
-    lr, ir = R.predict(img.permute(0, 3, 1, 2).float(), sd, "all", 0.5)
-    assert list(idx) == list(ir) and len(idx) > 0 and np.abs(lm - lr).max() < 2e-3
+    x = img.permute(0, 3, 1, 2).float()
+    lr, ir, ex = R.predict(x, sd, "all", 0.5, return_all=True)
+    assert list(idx) == list(ir) and len(idx) > 0
+    # north_star's tolerance (1e-3 px), measured against a float64 evaluation of the same faces: the GPU may be as far from the
+    # exact landmarks as the float32 oracle itself is (5e-7 .. 5e-5 px at these sizes) plus 1e-3, never more
+    l64 = R.landmarks_fp64(x, sd, ex)
+    e_gpu, e_ora = float(np.abs(lm - l64).max()), float(np.abs(lr - l64).max())
+    print(f"{hw}: |gpu - fp64| {e_gpu:.3g} px, |oracle - fp64| {e_ora:.3g} px, |gpu - oracle| {float(np.abs(lm - lr).max()):.3g} px")
+    assert e_gpu <= e_ora + 1e-3 and np.abs(lm - lr).max() < 1e-3
 
 
 @pytest.mark.parametrize("n,h,w", [(16, 160, 192), (19, 100, 136), (64, 256, 256)])
