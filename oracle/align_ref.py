@@ -249,8 +249,66 @@ def border_interpolate(p, length, border):
     raise ValueError(border)
 
 
-def warp_affine(image, M, dsize, border=0):
-    """image (h,w,3) uint8, M 2x3 forward transform, dsize=(width,height) -> (height,width,3) uint8."""
+def warp_affine_float32(image, M, dsize, border=0):
+    """The OTHER family of cv2.warpAffine(INTER_LINEAR) implementations: source coordinates and bilinear weights in float32,
+    one rounding to uint8 at the end (cvRound = round-half-even), as the SIMD "linear" warp kernels of recent OpenCV 4.x / 5.x
+    releases evaluate it, instead of the classic 5-bit-fraction / 15-bit-weight fixed-point tables that ``warp_affine``
+    restates (imgproc's WarpAffineInvoker + remapBilinear).  ``opencv-python`` is unpinned in the reference (setup.py:39), so
+    either may be what a user's wheel runs.  RESTATED FROM MEMORY OF THE PUBLISHED SOURCE, NOT PINNED: this variant exists so that
+    a fixture produced by such a wheel (tools/make_cv2_fixture.py records cv2.__version__ and the CPU dispatch) is recognisable
+    as "the float family, within one grey level of the fixed-point result" rather than as a defect; the HIP kernel implements
+    the classic algorithm.  Steps, all float32: inverse map as in ``warp_affine`` (float64, then rounded to float32);
+    sx = M0 x + M1 y + M2; ix = floor(sx), a = sx - ix; row lerp v0 = p00 + a (p01 - p00), v1 likewise; v = v0 + b (v1 - v0)."""
+    f = np.float32
+    img = np.asarray(image, np.uint8)
+    sh, sw = img.shape[:2]
+    ow, oh = int(dsize[0]), int(dsize[1])
+    m = np.asarray(M, np.float64).reshape(6).copy()
+    D = m[0] * m[4] - m[1] * m[3]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = m[4] * D, m[0] * D
+    m[0] = A11; m[1] *= -D; m[3] *= -D; m[4] = A22
+    b1 = -m[0] * m[2] - m[1] * m[5]
+    b2 = -m[3] * m[2] - m[4] * m[5]
+    m[2], m[5] = b1, b2
+    m = m.astype(f)
+    xs, ys = np.arange(ow, dtype=f)[None, :], np.arange(oh, dtype=f)[:, None]
+    sx = (xs * m[0] + (ys * m[1] + m[2]).astype(f)).astype(f)
+    sy = (xs * m[3] + (ys * m[4] + m[5]).astype(f)).astype(f)
+    ix, iy = np.floor(sx), np.floor(sy)
+    ax, ay = (sx - ix).astype(f)[..., None], (sy - iy).astype(f)[..., None]
+    ix, iy = np.clip(ix, -32768, 32767).astype(np.int64), np.clip(iy, -32768, 32767).astype(np.int64)
+    if border == 1:
+        ci = lambda p, n: np.clip(p, 0, n - 1)
+        x0, x1, y0, y1 = ci(ix, sw), ci(ix + 1, sw), ci(iy, sh), ci(iy + 1, sh)
+    else:
+        x0 = border_interpolate(ix, sw, border); x1 = border_interpolate(ix + 1, sw, border)
+        y0 = border_interpolate(iy, sh, border); y1 = border_interpolate(iy + 1, sh, border)
+
+    def tap(yy, xx):
+        okm = (yy >= 0) & (xx >= 0)
+        v = img[np.where(okm, yy, 0), np.where(okm, xx, 0)].astype(f)
+        return np.where(okm[..., None], v, f(0))
+
+    p00, p01, p10, p11 = tap(y0, x0), tap(y0, x1), tap(y1, x0), tap(y1, x1)
+    v0 = (p00 + ax * (p01 - p00)).astype(f)
+    v1 = (p10 + ax * (p11 - p10)).astype(f)
+    v = (v0 + ay * (v1 - v0)).astype(f)
+    out = np.clip(np.rint(v), 0, 255).astype(np.uint8)
+    if border == 0:
+        outside = (ix >= sw) | (ix + 1 < 0) | (iy >= sh) | (iy + 1 < 0)
+        out[outside] = 0
+    return out
+
+
+def warp_affine(image, M, dsize, border=0, variant="fixed"):
+    """image (h,w,3) uint8, M 2x3 forward transform, dsize=(width,height) -> (height,width,3) uint8.
+    ``variant``: "fixed" = OpenCV's classic fixed-point algorithm (what the HIP kernel implements), "float32" = the float
+    family of newer wheels (``warp_affine_float32``)."""
+    if variant == "float32":
+        return warp_affine_float32(image, M, dsize, border)
+    if variant != "fixed":
+        raise ValueError(f"unknown warp variant {variant!r}")
     img = np.asarray(image, np.uint8)
     sh, sw = img.shape[:2]
     ow, oh = int(dsize[0]), int(dsize[1])

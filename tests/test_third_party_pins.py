@@ -21,9 +21,34 @@ def _fixture(name):
         pytest.skip(f"tests/golden/{name} is absent (no cv2 / torchvision in the build container): parity of this row stays "
                     f"unpinned; {HOW}")
     z = np.load(path)
-    versions = {k: str(z[k]) for k in z.files if k.endswith("_version")}
+    versions = {k: str(z[k]) for k in z.files if k.endswith("_version") or k in ("cv2_build_cpu", "cv2_use_optimized", "machine")}
     print(f"tests/golden/{name}: generated with {versions}")                 # shown with `pytest -s` / `-rP`
     return z
+
+
+def _diff(a, b):
+    d = np.abs(a.astype(int) - b.astype(int))
+    return int(d.max()), float((d > 0).mean())
+
+
+def _warp_family(z):
+    """Which algorithm family of cv2.warpAffine(INTER_LINEAR) the fixture records, decided on ALL its warps against the two
+    oracle variants: "fixed" (classic 5-bit-fraction / 15-bit-weight tables: byte-exact) or "float32" (newer SIMD linear
+    kernels).  Returns (family, report lines)."""
+    from oracle import align_ref as A
+    worst = {"fixed": [0, 0.0], "float32": [0, 0.0]}
+    for k, img, mats, dsize in _warp_cases(z):
+        for b in BORDERS:
+            for j, m in enumerate(mats):
+                for variant in worst:
+                    mx, frac = _diff(A.warp_affine(img, m, dsize, A.BORDER[b], variant=variant), z[f"warp{k}_{b}"][j])
+                    worst[variant] = [max(worst[variant][0], mx), max(worst[variant][1], frac)]
+    # (the two families differ by up to several grey levels on noisy images: the fixed-point one quantises the source
+    #  coordinate to 1/32 px — so "which one is byte-exact, or within one rounding" decides, not their mutual distance)
+    family = "fixed" if worst["fixed"][0] == 0 else ("float32" if worst["float32"][0] <= 1 else "unknown")
+    lines = [f"cv2 {z['cv2_version']} warpAffine vs oracle variant {v!r}: max |d| = {w[0]}, worst fraction of differing bytes = {w[1]:.2e}"
+             for v, w in worst.items()]
+    return family, lines, worst
 
 
 # ------------------------------------------------------------------------------------------- a13: estimators
@@ -74,14 +99,25 @@ def _warp_cases(z):
 
 
 def test_oracle_warp_vs_opencv():
-    """Byte-exact: the fixed-point bilinear warp (AB_BITS 10, INTER_BITS 5, (sum + 2^14) >> 15) has no platform freedom."""
+    """The classic fixed-point bilinear warp (AB_BITS 10, INTER_BITS 5, (sum + 2^14) >> 15) has no platform freedom: a wheel
+    that runs it must match ``warp_affine`` byte for byte.  A wheel of the float family (newer SIMD linear kernels; the
+    reference leaves opencv-python unpinned) is recognised as such — reported with its version, CPU dispatch and the size of
+    the difference — and must then lie within one grey level of the fixed-point result; anything else is a defect."""
     from oracle import align_ref as A
     z = _fixture("opencv_align.npz")
-    for k, img, mats, dsize in _warp_cases(z):
-        for b in BORDERS:
-            for j, m in enumerate(mats):
-                got = A.warp_affine(img, m, dsize, A.BORDER[b])
-                assert np.array_equal(got, z[f"warp{k}_{b}"][j]), f"case {k}, border {b}, matrix {j}"
+    family, lines, worst = _warp_family(z)
+    print("\n".join(lines))
+    print(f"=> this fixture records the {family!r} family")
+    # "fixed": byte-exact by construction of _warp_family; "float32": within one rounding of the float restatement (which is
+    # written from memory of the published source: an exact match is not claimed); anything else is a defect to look at
+    assert family in ("fixed", "float32"), f"neither family explains this wheel's warpAffine: {lines}"
+    # the wheel's own portable path (optimised code switched off), when recorded, is the classic algorithm
+    if "warp0_constant_noopt" in z.files:
+        for k, img, mats, dsize in _warp_cases(z):
+            for b in BORDERS:
+                for j, m in enumerate(mats):
+                    mx, frac = _diff(A.warp_affine(img, m, dsize, A.BORDER[b]), z[f"warp{k}_{b}_noopt"][j])
+                    assert mx == 0, f"setUseOptimized(False) warp, case {k}, border {b}, matrix {j}: max |d| {mx}, {frac:.2e} of bytes"
 
 
 @pytest.mark.gpu
@@ -94,7 +130,18 @@ def test_kernel_warp_vs_opencv(device):
         dm = torch.from_numpy(mats.reshape(-1, 6)).to(device)
         for b in BORDERS:
             got = align.warp_affine(dimg, idx, dm, None, None, dsize, align.border_code(b)).cpu().numpy()
-            assert np.array_equal(got, z[f"warp{k}_{b}"]), f"case {k}, border {b}"
+            mx, frac = _diff(got, z[f"warp{k}_{b}"])
+            if mx:                       # say HOW it differs: a float-family wheel is a known other algorithm, a bug is not
+                from oracle import align_ref as A
+                family, lines, _ = _warp_family(z)
+                print(f"case {k}, border {b}: kernel vs cv2 max |d| = {mx}, {frac:.2e} of bytes; fixture family {family!r}; " + "; ".join(lines))
+                assert family == "float32", f"case {k}, border {b}: kernel differs from a fixed-point wheel"
+                # the kernel implements the classic algorithm: its distance from a float-family wheel must be exactly the
+                # distance between the two algorithms, i.e. the kernel still equals the fixed-point restatement byte for byte
+                fixed = np.stack([A.warp_affine(img, m, dsize, A.BORDER[b]) for m in mats])
+                assert np.array_equal(got, fixed), f"case {k}, border {b}"
+            if f"warp{k}_{b}_noopt" in z.files:
+                assert np.array_equal(got, z[f"warp{k}_{b}_noopt"]), f"case {k}, border {b}: portable-path wheel output"
 
 
 # ------------------------------------------------------------------------------------------- f1: resize + border

@@ -47,9 +47,25 @@ def photo_like(h, w, seed):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
+def describe_cv2(cv2):
+    """What produced the numbers: the wheel's version, the CPU baseline / dispatch lines of its build, whether its optimised
+    paths were on.  `opencv-python` is unpinned in the reference (setup.py:39) and its warp / resize kernels differ between
+    releases and CPU dispatch levels: a fixture must say which algorithm family it records."""
+    import platform
+    info = cv2.getBuildInformation()
+    keep = [ln.strip() for ln in info.splitlines()
+            if any(k in ln for k in ("Version control", "CPU/HW features", "Baseline:", "Dispatched code generation", "requested:",
+                                     "Use IPP", "Parallel framework", "Platform", "Host:"))
+            or ln.strip().startswith(("SSE", "AVX", "NEON", "FP16", "VSX", "RVV"))]
+    return {"cv2_version": np.array(cv2.__version__), "cv2_build_cpu": np.array(" | ".join(keep)),
+            "cv2_use_optimized": np.array(bool(cv2.useOptimized())), "cv2_num_threads": np.array(int(cv2.getNumThreads())),
+            "numpy_version": np.array(np.__version__), "python_version": np.array(platform.python_version()),
+            "machine": np.array(platform.machine() + " " + (platform.processor() or ""))}
+
+
 def make_align(cv2):
     rng = np.random.default_rng(101)
-    out = {"cv2_version": np.array(cv2.__version__)}
+    out = describe_cv2(cv2)
     # ---- estimators: 64 five-point sets (similarity-like faces at several scales / rotations + jitter) and degenerate ones
     tgt = standard_target(256, 256)
     srcs = []
@@ -85,6 +101,13 @@ def make_align(cv2):
         for b in BORDERS:
             mode = getattr(cv2, f"BORDER_{b.upper()}")
             out[f"warp{k}_{b}"] = np.stack([cv2.warpAffine(img, m, (ow, oh), borderMode=mode) for m in mats])
+            # the same calls with the wheel's optimised (IPP / HAL / SIMD-dispatch) paths switched off: the portable C++
+            # implementation of the same release, i.e. the other algorithm family when the two differ
+            cv2.setUseOptimized(False)
+            try:
+                out[f"warp{k}_{b}_noopt"] = np.stack([cv2.warpAffine(img, m, (ow, oh), borderMode=mode) for m in mats])
+            finally:
+                cv2.setUseOptimized(True)
         k += 1
     out["warp_cases"] = np.array(k)
     np.savez_compressed(os.path.join(GOLDEN, "opencv_align.npz"), **out)
@@ -94,7 +117,7 @@ def make_align(cv2):
 def make_batch(cv2):
     """utils.py:320-335 for down-scaling (INTER_AREA) and up-scaling (INTER_CUBIC) inputs, integer and non-integer ratios,
     plus the five border types of copyMakeBorder."""
-    out = {"cv2_version": np.array(cv2.__version__)}
+    out = describe_cv2(cv2)
     cases = [((270, 480), 128), ((135, 240), 256), ((600, 400), 200), ((301, 517), 224), ((64, 48), 160), ((540, 960), 256)]
     for k, ((h, w), size) in enumerate(cases):
         img = photo_like(h, w, 300 + k)
@@ -132,7 +155,7 @@ def make_resnet():
     with torch.no_grad():
         feats = body(x)
     np.savez_compressed(os.path.join(GOLDEN, "torchvision_resnet50.npz"), x=x.numpy(),
-                        torchvision_version=np.array(torchvision.__version__),
+                        torchvision_version=np.array(torchvision.__version__), torch_version=np.array(torch.__version__),
                         **{f"feat{k}": v.numpy() for k, v in feats.items()})
     print("wrote torchvision_resnet50.npz", {k: tuple(v.shape) for k, v in feats.items()})
 
