@@ -330,11 +330,86 @@ __device__ __forceinline__ void conv_epilogue_regs(const ConvK& p, f32x16 (&acc)
     const unsigned r0 = r[0], r1 = r[1];
     x = __uint_as_float(r0); y = __uint_as_float(r1);
   };
-  fcp_static_for<0, TN>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    const int co = co_tile + wn * WTN + j * 32 + 8 * lg;            // this lane's eight channels in column tile j
+  // Issue order of the vector memory (round 5).  The first version loaded a set's residual, waited, computed, stored, and
+  // went on to the next set: the stores may alias the residual as far as the compiler can tell, so it never moved a load
+  // above an earlier store, and vmcnt retires in order — every one of the 2 TM TN sets waited for its own HBM round trip AND
+  // for the acknowledgement of the previous set's stores (16 serial round trips per 256 x 256 tile with a residual: the
+  // 1x1 expand + identity convs and the FPN merges spent two thirds of their time there).  Now the sets are handled in GROUPS
+  // of up to two row tiles of one column tile (<= 4 sets): the residual pieces of the whole group are requested first (8
+  // registers per set), THEN the finished previous group is stored, then the group is computed into registers: one exposed
+  // round trip per group, and no wait ever sits behind a store.
+  constexpr int GI = TM < 2 ? TM : 2;                              // row tiles per group
+  constexpr int NGI = (TM + GI - 1) / GI;                          // groups per column tile
+  constexpr int NG = TN * NGI;
+  u32x4_t pend_a[GI][2], pend_b[GI][2];                            // finished values of the previous group (hi | lo, or 2 x f32x4)
+  auto row_of = [&](int i, int set) { return m_start + wm * WTM + i * 32 + 16 * set + lp; };
+  auto chan_of = [&](int jj) { return co_tile + wn * WTN + jj * 32 + 8 * lg; };
+  auto flush = [&](auto gc) {                                      // stores of group g
+    constexpr int g = decltype(gc)::value, jj = g / NGI, i0 = (g % NGI) * GI;
+    const int co = chan_of(jj);
+    fcp_static_for<0, GI>([&](auto ic) {
+      constexpr int i = i0 + decltype(ic)::value;
+      if constexpr (i < TM) {
+        fcp_static_for<0, 2>([&](auto sc) {
+          constexpr int set = decltype(sc)::value;
+          const int mi = row_of(i, set);
+          if (i < tm_act && mi < m_end && co < co_end) {
+            if (p.out_fmt == 1) {
+              char* ob = reinterpret_cast<char*>(p.out) + (long)mi * p.out_ld * 4 + split_chan_off(co);
+              *reinterpret_cast<u32x4_t*>(ob) = pend_a[i - i0][set];
+              *reinterpret_cast<u32x4_t*>(ob + 64) = pend_b[i - i0][set];
+            } else {
+              float* dst = p.out + (long)mi * p.out_ld + co;
+              *reinterpret_cast<u32x4_t*>(dst) = pend_a[i - i0][set];
+              *reinterpret_cast<u32x4_t*>(dst + 4) = pend_b[i - i0][set];
+            }
+          }
+        });
+      }
+    });
+  };
+  fcp_static_for<0, NG>([&](auto gc) {
+    constexpr int g = decltype(gc)::value, j = g / NGI, i0 = (g % NGI) * GI;
+    const int co = chan_of(j);                                      // this lane's eight channels in column tile j
     const bool cok = co < co_end;
     const int cc = cok ? co : co_tile;
+    // ---- the group's residual pieces (raw 16-byte loads, decoded at use)
+    u32x4_t r1a[GI][2], r1b[GI][2];
+    if (p.res1 != nullptr) {
+      fcp_static_for<0, GI>([&](auto ic) {
+        constexpr int i = i0 + decltype(ic)::value;
+        if constexpr (i < TM) {
+          fcp_static_for<0, 2>([&](auto sc) {
+            constexpr int set = decltype(sc)::value;
+            const int mi = row_of(i, set);
+            const long m = (i < tm_act && mi < m_end && cok) ? (long)mi : (long)m_start;
+            long rpix = m;
+            if (p.res1_resize) {
+              const int ni = (int)(m / hw);
+              const int rem = (int)(m - (long)ni * hw);
+              const int ho = rem / p.out_w;
+              const int wo = rem - ho * p.out_w;
+              int sh = (int)floorf(ho * p.res1_sh);
+              int sw = (int)floorf(wo * p.res1_sw);
+              sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
+              sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
+              rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
+            }
+            if (p.res1_fmt == 1) {
+              const char* pb = reinterpret_cast<const char*>(p.res1) + rpix * p.res1_ld * 4 + split_chan_off(cc);
+              r1a[i - i0][set] = *reinterpret_cast<const u32x4_t*>(pb);
+              r1b[i - i0][set] = *reinterpret_cast<const u32x4_t*>(pb + 64);
+            } else {
+              r1a[i - i0][set] = *reinterpret_cast<const u32x4_t*>(p.res1 + rpix * p.res1_ld + cc);
+              r1b[i - i0][set] = *reinterpret_cast<const u32x4_t*>(p.res1 + rpix * p.res1_ld + cc + 4);
+            }
+          });
+        }
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (g > 0) flush(std::integral_constant<int, g - 1>{});   // the previous group's stores, behind this group's loads
+    __builtin_amdgcn_sched_barrier(0);
     float bias8[8], ws8[8];
     {
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wscale + cc), w1 = *reinterpret_cast<const f32x4*>(p.wscale + cc + 4);
@@ -343,68 +418,57 @@ __device__ __forceinline__ void conv_epilogue_regs(const ConvK& p, f32x16 (&acc)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { ws8[e] = w0[e]; ws8[4 + e] = w1[e]; bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
-    fcp_static_for<0, TM>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      float va[8], vb[8];                                           // sets A / B after the permutations
-      fcp_static_for<0, 4>([&](auto ec) {
-        constexpr int e = decltype(ec)::value;
-        // (named floats: __builtin_bit_cast applied directly to a vector-element expression read element 0)
-        float q0 = acc[i][j][e], q1 = acc[i][j][4 + e], q2 = acc[i][j][8 + e], q3 = acc[i][j][12 + e];
-        swap32(q0, q1);               // q0: ch e (lanes 0-31) | 8 + e (32-63);   q1: 4 + e | 12 + e           of pixel l & 31
-        swap32(q2, q3);               // q2: 16 + e | 24 + e;                     q3: 20 + e | 28 + e
-        swap32(q0, q2); swap16(q0, q2);   // q0 = set A: rows of 16 lanes hold ch e, 8 + e, 16 + e, 24 + e of pixels 0-15; q2 = set B (pixels 16-31)
-        swap32(q1, q3); swap16(q1, q3);   // the same for ch 4 + e, 12 + e, 20 + e, 28 + e
-        va[e] = q0; va[4 + e] = q1; vb[e] = q2; vb[4 + e] = q3;
-      });
-      fcp_static_for<0, 2>([&](auto sc) {
-        constexpr int set = decltype(sc)::value;
-        float (&v)[8] = set == 0 ? va : vb;
-        const int mi = m_start + wm * WTM + i * 32 + 16 * set + lp;
-        const bool ok = i < tm_act && mi < m_end && cok;
-        const long m = ok ? (long)mi : (long)m_start;
-        float r1[8], r2[8];
-        if (p.res1 != nullptr) {
-          long rpix = m;
-          if (p.res1_resize) {
-            const int ni = (int)(m / hw);
-            const int rem = (int)(m - (long)ni * hw);
-            const int ho = rem / p.out_w;
-            const int wo = rem - ho * p.out_w;
-            int sh = (int)floorf(ho * p.res1_sh);
-            int sw = (int)floorf(wo * p.res1_sw);
-            sh = sh < p.res1_h - 1 ? sh : p.res1_h - 1;
-            sw = sw < p.res1_w - 1 ? sw : p.res1_w - 1;
-            rpix = ((long)ni * p.res1_h + sh) * p.res1_w + sw;
+    fcp_static_for<0, GI>([&](auto ic) {
+      constexpr int i = i0 + decltype(ic)::value;
+      if constexpr (i < TM) {
+        float va[8], vb[8];                                           // sets A / B after the permutations
+        fcp_static_for<0, 4>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          // (named floats: __builtin_bit_cast applied directly to a vector-element expression read element 0)
+          float q0 = acc[i][j][e], q1 = acc[i][j][4 + e], q2 = acc[i][j][8 + e], q3 = acc[i][j][12 + e];
+          swap32(q0, q1);               // q0: ch e (lanes 0-31) | 8 + e (32-63);   q1: 4 + e | 12 + e           of pixel l & 31
+          swap32(q2, q3);               // q2: 16 + e | 24 + e;                     q3: 20 + e | 28 + e
+          swap32(q0, q2); swap16(q0, q2);   // q0 = set A: rows of 16 lanes hold ch e, 8 + e, 16 + e, 24 + e of pixels 0-15; q2 = set B (pixels 16-31)
+          swap32(q1, q3); swap16(q1, q3);   // the same for ch 4 + e, 12 + e, 20 + e, 28 + e
+          va[e] = q0; va[4 + e] = q1; vb[e] = q2; vb[4 + e] = q3;
+        });
+        fcp_static_for<0, 2>([&](auto sc) {
+          constexpr int set = decltype(sc)::value;
+          float (&v)[8] = set == 0 ? va : vb;
+          float r1[8], r2[8];
+          if (p.res1 != nullptr) {
+            if (p.res1_fmt == 1) {
+              join8(r1a[i - i0][set], r1b[i - i0][set], r1);
+            } else {
+              const f32x4 fa = __builtin_bit_cast(f32x4, r1a[i - i0][set]), fb = __builtin_bit_cast(f32x4, r1b[i - i0][set]);
+              r1[0] = fa[0]; r1[1] = fa[1]; r1[2] = fa[2]; r1[3] = fa[3]; r1[4] = fb[0]; r1[5] = fb[1]; r1[6] = fb[2]; r1[7] = fb[3];
+            }
           }
-          load8(p.res1, rpix, p.res1_ld, cc, p.res1_fmt, r1);
-        }
-        if (p.res2 != nullptr) load8(p.res2, m, p.res2_ld, cc, p.res2_fmt, r2);
+          if (p.res2 != nullptr) {
+            const int mi = row_of(i, set);
+            load8(p.res2, (i < tm_act && mi < m_end && cok) ? (long)mi : (long)m_start, p.res2_ld, cc, p.res2_fmt, r2);
+          }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = v[e] * ws8[e] + bias8[e];
-          if (p.res1 != nullptr && p.res1_pre) x += r1[e];
-          x = x >= 0.f ? x : x * p.act_slope;
-          x = x * p.alpha;
-          if (p.res1 != nullptr && !p.res1_pre) x += r1[e];
-          if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
-          v[e] = x;
-        }
-        if (ok) {
-          if (p.out_fmt == 1) {
-            u32x4_t hi, lo;
-            split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
-            char* ob = reinterpret_cast<char*>(p.out) + m * p.out_ld * 4 + split_chan_off(co);
-            *reinterpret_cast<u32x4_t*>(ob) = hi;
-            *reinterpret_cast<u32x4_t*>(ob + 64) = lo;
-          } else {
-            float* dst = p.out + m * p.out_ld + co;
-            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e] * ws8[e] + bias8[e];
+            if (p.res1 != nullptr && p.res1_pre) x += r1[e];
+            x = x >= 0.f ? x : x * p.act_slope;
+            x = x * p.alpha;
+            if (p.res1 != nullptr && !p.res1_pre) x += r1[e];
+            if (p.res2 != nullptr) x = x * p.alpha2 + r2[e];
+            v[e] = x;
           }
-        }
-      });
+          if (p.out_fmt == 1) {
+            split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, pend_a[i - i0][set], pend_b[i - i0][set]);
+          } else {
+            pend_a[i - i0][set] = __builtin_bit_cast(u32x4_t, f32x4{v[0], v[1], v[2], v[3]});
+            pend_b[i - i0][set] = __builtin_bit_cast(u32x4_t, f32x4{v[4], v[5], v[6], v[7]});
+          }
+        });
+      }
     });
   });
+  flush(std::integral_constant<int, NG - 1>{});
 }
 
 // Epilogue for 8-channel granularity: used whenever the output or a residual is in split32 format
