@@ -38,19 +38,38 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int PH = 5, PW = 16;                 // pooled pixels per patch
-constexpr int SH = 2 * PH + 1, SW = 2 * PW + 1;  // stem pixels per patch: 11 x 33
-constexpr int NSTEM = SH * SW;                 // 363
-constexpr int NTILES = (NSTEM + 31) / 32;      // 12 = 3 per row-tile group
+constexpr int PH = 5;                          // pooled rows per patch
+constexpr int SH = 2 * PH + 1;                 // stem rows per patch: 11
 constexpr int IH = 2 * SH + 5;                 // 27 image rows (+1 spare row for the padded K chunk)
-constexpr int IWB = (2 * SW + 5) * 3;          // 213 bytes per image row of the patch
-constexpr int IPITCH = 216;                    // binary16 elements per staged image row
-constexpr int IN_ELEMS = (IH + 1) * IPITCH;    // 6048 halves = 12 096 B
-constexpr int NT = 512;                         // 8 waves: (row-tile group 0..3) x (column tile 0..1)
-constexpr int TPR = 18;                        // threads per patch row: 27 x 18 = 486 of the 512 fetch; 18 = 6 pixels x 3
-constexpr int NLOAD = (IWB + TPR - 1) / TPR;   // 12 bytes per thread: columns c0 + 18 j of its row
 constexpr int SPITCH = 68;                     // floats per staged stem pixel (64 + 4: conflict-free pooling)
 constexpr int KSTEPS = 11;                     // 22 chunks of 8 K values (7 rows x 3 chunks, +1 zero chunk)
+
+// Patch geometry as a function of the patch width PW (pooled pixels): 16 = the product form, 512 threads, one workgroup per CU;
+// 8 = 256 threads and 74 KiB of LDS, TWO workgroups per CU (round 5).  A patch runs as a sequence of phases separated by
+// workgroup barriers (commit -> MFMAs -> pooling + stores -> conv1 -> its epilogue), the matrix pipe being busy in one of them
+// only (23 % of the cycles in the round-3 probes): the idea was that two independent workgroups per CU put one's MFMA phase beside
+// the other's LDS / store phases.  Same work per wave and patch (3 row tiles x 11 k-steps), same K order per stem pixel, same
+// bits (tools/stem_hash.py: identical digest) — and 8.8 % SLOWER in an in-call A/B (689.7 vs 634.0 us: +10 % image bytes and +3 %
+// stem pixels per pooled pixel for the narrower halo, and no overlap gained: profiles/r05_probes.md section 3).  Kept as a
+// build-time geometry (-DFCP_STEM_PW=8) for that record.
+template <int PW_>
+struct StemGeo {
+  static constexpr int PW = PW_;
+  static constexpr int SW = 2 * PW + 1;                    // stem columns per patch: 33 | 17
+  static constexpr int NSTEM = SH * SW;                    // 363 | 187
+  static constexpr int NTILES = (NSTEM + 31) / 32;         // 12 | 6 row tiles of 32 stem pixels
+  static constexpr int IWB = (2 * SW + 5) * 3;             // 213 | 117 bytes per image row of the patch
+  static constexpr int IPITCH = 6 * SW + 18;               // 216 | 120 binary16 elements per staged image row (a lane's last K chunk ends at 6 SW + 17)
+  static constexpr int IN_ELEMS = (IH + 1) * IPITCH;
+  static constexpr int NT = 32 * PW;                       // threads: the pooling pass is (32 channel pairs) x (PW pooled columns)
+  static constexpr int NGRP = NT / 128;                    // row-tile groups: waves = NGRP x 2 column tiles
+  static constexpr int TPR = NT / 28;                      // threads per patch row: 18 | 9 (a whole number of pixels: 6 | 3)
+  static constexpr int NLOAD = (IWB + TPR - 1) / TPR;      // 12 | 13 bytes per thread: columns c0 + TPR j of its row
+  static constexpr int C1ROWS = (PH * PW + 31) / 32 * 32;  // the patch's pooled pixels padded to MFMA row tiles: 96 | 64
+  static constexpr int C1_BYTES = C1ROWS * 2 * 128;        // conv1 operand image: [rows][2 channel slices][128 B]
+  static constexpr int WGS = PW <= 8 ? 2 : 1;              // workgroups per CU
+  static_assert(TPR % 3 == 0 && IH * TPR <= NT && IPITCH % 2 == 0 && NTILES % NGRP == 0, "stem patch geometry");
+};
 
 struct StemParams {
   const uint8_t* img;
@@ -69,8 +88,6 @@ struct StemParams {
   int t1_ld;
 };
 
-constexpr int C1ROWS = 96;                     // the 80 pooled pixels of a patch padded to three MFMA row tiles
-constexpr int C1_BYTES = C1ROWS * 2 * 128;     // conv1 operand image: [96 rows][2 channel slices][128 B]
 constexpr int CPITCH = 68;                     // floats per pixel of conv1's fp32 staging tile (in the stem stage region)
 __device__ __forceinline__ int swz1(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 
@@ -82,8 +99,12 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <bool HAS_C1>
-__global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
+template <bool HAS_C1, int PW_>
+__global__ void __launch_bounds__(StemGeo<PW_>::NT, StemGeo<PW_>::WGS) stem_pool_kernel(const StemParams p) {
+  using G = StemGeo<PW_>;
+  constexpr int PW = G::PW, SW = G::SW, NSTEM = G::NSTEM, NTILES = G::NTILES, IWB = G::IWB, IPITCH = G::IPITCH;
+  constexpr int IN_ELEMS = G::IN_ELEMS, NT = G::NT, NGRP = G::NGRP, TPR = G::TPR, NLOAD = G::NLOAD, C1ROWS = G::C1ROWS;
+  constexpr int KPG = NTILES / NGRP;                                // row tiles per wave: 3
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ __attribute__((aligned(16))) _Float16 inh[IN_ELEMS];   // (x - mean) as binary16: exact integers
   float* stage = smem;
@@ -110,14 +131,14 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
   const float ws2a = p.wscale[pc2], ws2b = p.wscale[pc2 + 1], bias2a = p.bias[pc2], bias2b = p.bias[pc2 + 1];
   float ws1a = 0.f, ws1b = 0.f, b1a = 0.f, b1b = 0.f;
   if constexpr (HAS_C1) { ws1a = p.ws1[pc2]; ws1b = p.ws1[pc2 + 1]; b1a = p.b1[pc2]; b1b = p.b1[pc2 + 1]; }
-  // HAS_C1: waves 0..5 own one 32 x 32 tile of the 96 x 64 conv1 output each (row tile wave >> 1, filters (wave & 1) * 32 ..).
+  // HAS_C1: waves 0 .. 2 C1ROWS / 32 - 1 own one 32 x 32 tile of the C1ROWS x 64 conv1 output each (row tile wave >> 1, filters (wave & 1) * 32 ..).
   // Its filter fragments — 2 channel slices x 2 k-halves x hi / lo, 8 KiB for the whole conv, L1-resident — are fetched per
   // patch (the stem's 22 fragments fill the register file).  K order and term order are those of conv_igemm_f16x3_dma
   // (slices ascending; per k-half al*bh, ah*bl, ah*bh): same bits.
   const int c1rt = wave >> 1, c1ct = wave & 1;
 
-  // this thread's share of the image patch: bytes c0 + 18 * j (j = 0 .. 11) of patch row tid / 18.  18 is a whole number
-  // of pixels, so the channel (and its mean), the row and its clamp are per thread, the pixel column advances by 6 per
+  // this thread's share of the image patch: bytes c0 + TPR * j (j = 0 .. NLOAD - 1) of patch row tid / TPR.  TPR is a whole number
+  // of pixels, so the channel (and its mean), the row and its clamp are per thread, the pixel column advances by TPR / 3 per
   // byte and the LDS offsets are immediates: four registers of bookkeeping and ~5 vector instructions per byte each for
   // the fetch and the commit (a flat byte index took 48 registers and three times the arithmetic).
   const int frow = tid / TPR, fc0 = tid - frow * TPR;          // rows >= IH (threads 486 ..) fetch nothing
@@ -140,7 +161,7 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
     pre_ok = 0u;
 #pragma unroll
     for (int j = 0; j < NLOAD; ++j) {
-      const int x = ix0 + fx0 + 6 * j;
+      const int x = ix0 + fx0 + (TPR / 3) * j;
       pre_ok |= (rowok && (unsigned)x < (unsigned)p.w) ? (1u << j) : 0u;
       pre[j] = base[(unsigned)(min(max(x, 0), p.w - 1) * 3)];
     }
@@ -158,10 +179,10 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
   __syncthreads();
 
   // image-patch byte offset of this lane's stem pixel in each of the wave's row tiles (patch independent)
-  int abase_t[(NTILES + 3) / 4];
+  int abase_t[KPG];
 #pragma unroll
-  for (int k = 0; k < (NTILES + 3) / 4; ++k) {
-    int pix = (grp + 4 * k) * 32 + (lane & 31);
+  for (int k = 0; k < KPG; ++k) {
+    int pix = (grp + NGRP * k) * 32 + (lane & 31);
     pix = pix < NSTEM ? pix : NSTEM - 1;
     const int si = pix / SW, sj = pix - si * SW;
     abase_t[k] = (2 * si) * IPITCH + 6 * sj;
@@ -183,9 +204,8 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
     const bool interior = sy0 >= 0 && sy0 + SH <= p.hs && sx0 >= 0 && sx0 + SW <= p.ws;   // workgroup-uniform
 
 #pragma unroll
-    for (int k = 0; k < (NTILES + 3) / 4; ++k) {
-      const int t = grp + 4 * k;
-      if (t >= NTILES) break;
+    for (int k = 0; k < KPG; ++k) {
+      const int t = grp + NGRP * k;
       const int abase = abase_t[k];
       f32x16 acc;
 #pragma unroll
@@ -236,7 +256,7 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
     // HAS_C1: conv1's filter fragments (8 x 16 B per lane, L1-resident) are requested here, a pooling pass ahead of use
     f16x8 c1w[8];
     if constexpr (HAS_C1) {
-      if (c1rt < 3) {
+      if (c1rt < C1ROWS / 32) {
         const char* wrow = p.w1 + (size_t)(c1ct * 32 + (lane & 31)) * 256;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
@@ -296,7 +316,7 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
       // possibly NaN / Inf bit patterns.  That is harmless only because the tile is accumulated TRANSPOSED (filters x
       // pixels): a pixel's operand row feeds exactly one accumulator column, and the columns of those rows are never
       // stored.  Any cross-pixel reduction or a change of the tile orientation must zero c1in first.
-      if (c1rt < 3) {
+      if (c1rt < C1ROWS / 32) {
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -348,6 +368,10 @@ __global__ void __launch_bounds__(NT, 1) stem_pool_kernel(const StemParams p) {
 
 }  // namespace
 
+#ifndef FCP_STEM_PW
+#define FCP_STEM_PW 16     // pooled pixels per patch row: 16 = one 8-wave workgroup per CU; 8 = two 4-wave workgroups (round 5: same bits, 8.8 % slower)
+#endif
+
 extern "C" int fcp_stem7x7s2_relu_pool_conv1_u8(const uint8_t* images, int n, int h, int w, const int32_t* mean_rgb,
                                                 const void* wfrag, const float* bias, const float* wscale, float* out,
                                                 int out_ld, int out_fmt, const void* w1, const float* ws1, const float* b1,
@@ -372,21 +396,22 @@ extern "C" int fcp_stem7x7s2_relu_pool_conv1_u8(const uint8_t* images, int n, in
   p.hs = (h + 6 - 7) / 2 + 1; p.ws = (w + 6 - 7) / 2 + 1;
   p.hp = (p.hs + 2 - 3) / 2 + 1; p.wp = (p.ws + 2 - 3) / 2 + 1;
   p.out_ld = out_ld; p.out_fmt = out_fmt;
-  p.tiles_y = fcp_cdiv(p.hp, PH); p.tiles_x = fcp_cdiv(p.wp, PW);
+  p.tiles_y = fcp_cdiv(p.hp, PH); p.tiles_x = fcp_cdiv(p.wp, StemGeo<FCP_STEM_PW>::PW);
   const long np = (long)n * p.tiles_y * p.tiles_x;
   FCP_REQUIRE(np < (1L << 31) && (long)n * h * w * 3 < (1L << 40), "stem: batch too large");
   p.npatches = (int)np;
   for (int c = 0; c < 3; ++c) p.mean[c] = mean_rgb[c];
   p.w1 = static_cast<const char*>(w1); p.ws1 = ws1; p.b1 = b1; p.t1 = t1; p.t1_ld = t1_ld;
-  const size_t lds = (size_t)NSTEM * SPITCH * 4 + (has_c1 ? C1_BYTES : 0);   // stem staging (+ conv1's operand image); the binary16 image patch is a static array
-  const int cus = fcp_cu_count();
+  using G = StemGeo<FCP_STEM_PW>;
+  const size_t lds = (size_t)G::NSTEM * SPITCH * 4 + (has_c1 ? G::C1_BYTES : 0);   // stem staging (+ conv1's operand image); the binary16 image patch is a static array
+  const int cus = fcp_cu_count() * G::WGS;
   const int grid = (int)(np < cus ? np : cus);
   if (has_c1) {
-    FCP_LDS_OPT_IN(&stem_pool_kernel<true>, lds);
-    hipLaunchKernelGGL(stem_pool_kernel<true>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, p);
+    FCP_LDS_OPT_IN((&stem_pool_kernel<true, FCP_STEM_PW>), lds);
+    hipLaunchKernelGGL((stem_pool_kernel<true, FCP_STEM_PW>), dim3(grid), dim3(G::NT), lds, (hipStream_t)stream, p);
   } else {
-    FCP_LDS_OPT_IN(&stem_pool_kernel<false>, lds);
-    hipLaunchKernelGGL(stem_pool_kernel<false>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, p);
+    FCP_LDS_OPT_IN((&stem_pool_kernel<false, FCP_STEM_PW>), lds);
+    hipLaunchKernelGGL((stem_pool_kernel<false, FCP_STEM_PW>), dim3(grid), dim3(G::NT), lds, (hipStream_t)stream, p);
   }
   FCP_LAUNCH_OK();
   return 0;
