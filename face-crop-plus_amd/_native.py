@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfcp_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_f32p = C.c_void_p
 _lib = None
@@ -46,8 +46,9 @@ CHAIN_OUT_EVEN_ONLY = 1  # fcp_chain_desc.flags: FCP_CHAIN_OUT_EVEN_ONLY
 class ChainDesc(C.Structure):
     """Mirror of ``fcp_chain_desc``."""
     _fields_ = [(k, C.c_void_p) for k in ("t1", "w2", "ws2", "b2", "w3", "ws3", "b3", "res", "out", "w1n", "ws1n",
-                                          "b1n", "t1n")] + \
-               [(k, C.c_int32) for k in ("n", "h", "w", "c", "cn", "t1_ld", "res_ld", "out_ld", "t1n_ld", "nout", "tile_m", "flags")]
+                                          "b1n", "t1n", "t1b")] + \
+               [(k, C.c_int32) for k in ("n", "h", "w", "c", "cn", "t1_ld", "res_ld", "out_ld", "t1n_ld", "nout", "tile_m", "flags",
+                                         "cb", "t1b_ld", "t1b_h", "t1b_w", "t1b_stride")]
 
 
 # name -> argtypes; every function returns int (0 = ok)

@@ -56,6 +56,9 @@ struct ChainK {
   int n, h, w, M;
   int nt_store;
   int out_even;     // patch form: store `out` at even (y, x) only (FCP_CHAIN_OUT_EVEN_ONLY)
+  // two-source pair (DIRECT forms): the trailing channels of conv3's input come from t1b, a split32 tensor (n, hb, wb, t1b_ld)
+  // sampled at (y * sb, x * sb) — the K concatenation [conv2 out | x(::s, ::s)] of a stride-2 bottleneck's conv3 + downsample
+  const float* t1b; unsigned t1b_bytes; int t1b_ld, hb, wb, sb;
 };
 
 // Pixels per workgroup tile: BMT = 128 (4 waves, up to two workgroups per CU; the default) or 256 (8 waves, one workgroup per
@@ -78,11 +81,17 @@ constexpr int r0_bytes(int bmt, int cw, int cn, bool has_c2) { return has_c2 ? 2
 // (144 + 128 KiB otherwise) and brings the 128-wide pairs down to 80 KiB: TWO workgroups per CU, the second one's
 // MFMAs under the first one's epilogue (FCP_CHAIN_NOALIAS: the 128-wide pairs as before, 128-144 KiB, one per CU).
 constexpr bool alias_t2(int bmt, int cw, int cn, bool has_c2) { return !has_c2; }
-constexpr int lds_bytes(int bmt, int cw, int cn, bool has_c2) {   // 80 KiB (two per CU) | 112-160 KiB
+// DIRECT (two-source pair forms, round 5): the operand tile never exists in LDS at all — a lane's fragments are 16-byte pieces of
+// the split32 pixel rows, i.e. plain buffer loads straight into the registers they live in for the whole chunk loop (a
+// 128 x 384-channel tile is 192 KiB: it fits neither LDS nor an alias of the chunk buffers); LDS holds the chunk buffers only.
+constexpr int lds_bytes(int bmt, int cw, int cn, bool has_c2, bool direct = false) {   // 80 KiB (two per CU) | 112-160 KiB
   const int r0 = r0_bytes(bmt, cw, cn, has_c2), t2 = bmt * cw * 4;
+  if (direct) return r0;
   return !alias_t2(bmt, cw, cn, has_c2) ? r0 + t2 : (r0 > w1b_off(bmt) + t2 ? r0 : w1b_off(bmt) + t2);
 }
-constexpr int wgs_per_cu(int bmt, int cw, int cn, bool has_c2) { return bmt == 128 && lds_bytes(bmt, cw, cn, has_c2) <= 80 * 1024 ? 2 : 1; }
+constexpr int wgs_per_cu(int bmt, int cw, int cn, bool has_c2, bool direct = false) {
+  return bmt == 128 && !direct && lds_bytes(bmt, cw, cn, has_c2) <= 80 * 1024 ? 2 : 1;   // (the DIRECT forms hold 48 fragments: one wave per SIMD)
+}
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 
@@ -100,8 +109,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // one-KiB vector-memory instructions a tile issues — and the chain kernels are bound by exactly that path
 // (profiles/r04_probes.md section 1: same cycles with and without their MFMAs).  The halo form issues 46.  Same K order (channel
 // slice outer, taps inner), same terms: bit-identical.
-template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false>
-__global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT / 128) bneck_chain_c64(const ChainK p) {
+template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false, int CW2 = 0>
+__global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, CW2 > 0) * BMT / 128) bneck_chain_c64(const ChainK p) {
+  constexpr bool DIRECT = CW2 > 0;                  // two-source pair: CW - CW2 channels from t1, CW2 from t1b; fragments loaded straight from global memory
+  static_assert(!DIRECT || (!HAS_C2 && BMT == 128 && CW2 % 32 == 0 && CW2 < CW), "two-source forms are pair forms on 128-pixel tiles");
   static_assert(!HAS_C2 || CW == C, "phase 1 is written for 64-channel bottlenecks");
   static_assert(!PATCH || HAS_C2, "the patch form is a conv2 form");
   constexpr int PH = BMT / 16;                      // PATCH: rows of the (PH x 16)-pixel patch: 8 (4 waves) or 16 (8 waves)
@@ -115,11 +126,11 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   constexpr int CS = CW / 32;                       // K slices of conv3
   constexpr int NCH = NOUT / 32;                    // groups of 32 conv3 filters
   constexpr int W3CH = CW * 128;                    // bytes of one conv3 filter group in LDS
-  constexpr bool ALIAS = alias_t2(BMT, CW, CN, HAS_C2);
+  constexpr bool ALIAS = alias_t2(BMT, CW, CN, HAS_C2) && !DIRECT;
   constexpr int T2_OFF = ALIAS ? W1B_OFF : r0_bytes(BMT, CW, CN, HAS_C2);
-  constexpr int WGS = wgs_per_cu(BMT, CW, CN, HAS_C2);
+  constexpr int WGS = wgs_per_cu(BMT, CW, CN, HAS_C2, DIRECT);
   constexpr int WPS = WGS * NW / 4;                 // waves per SIMD: 2 = 256 registers per wave
-  static_assert(lds_bytes(BMT, CW, CN, HAS_C2) <= 160 * 1024, "LDS budget");
+  static_assert(lds_bytes(BMT, CW, CN, HAS_C2, DIRECT) <= 160 * 1024, "LDS budget");
   constexpr bool W1DB = w1_double(BMT, CN, HAS_C2);
   // The next chunk's filter DMAs: one at a time BETWEEN the phase-2 MFMAs, or as a burst at the top of the chunk.  An LDS-DMA
   // instruction holds its wave until the vector-memory path has taken it.  With ONE wave per SIMD (the one-workgroup pair
@@ -137,7 +148,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   constexpr bool ROT = false;
   constexpr int PQ = ROT ? TN3 / CS : 0;                // phase-3 MFMAs behind every phase-2 MFMA (6 TN3 against 6 CS)
   static_assert(!ROT || (TN3 % CS == 0 && PQ >= 1), "rotated loop: TN3 must be a multiple of CS");
-  constexpr bool W1PRE = !ROT && W1DB && (HAS_C2 ? CN <= 64 || WPS == 1 : CN <= 128 && WPS == 1);   // conv1' fragments of a chunk requested under phase 2 (registers permitting)
+  constexpr bool W1PRE = !ROT && W1DB && !DIRECT && (HAS_C2 ? CN <= 64 || WPS == 1 : CN <= 128 && WPS == 1);   // conv1' fragments of a chunk requested under phase 2 (registers permitting)
   constexpr int W3B_OFF = w3b_off(BMT, CN, HAS_C2);
   static_assert(!HAS_C2 || W3B_OFF + 2 * W3CH <= 2 * STAGE, "chunk buffers must fit the phase-1 stage region");
   constexpr int NRES = HAS_RES ? 4 : 0;             // residual loads per chunk and thread
@@ -451,7 +462,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     __builtin_amdgcn_sched_barrier(0);
 
     conv2_epilogue(acc1, wm, wn);
-  } else {
+  } else if constexpr (!DIRECT) {
     // ---- no conv2: the operand tile is the input itself (CS slices of 128 pixels x 128 B), by LDS-DMA
     __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t1), 0, p.t1_bytes, 0x00020000);
 #pragma unroll
@@ -573,6 +584,48 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
         al[sl][s] = *reinterpret_cast<const f16x8*>(a2base + sl * BMT * ROWB + offL[s]);
       }
   };
+  if constexpr (DIRECT) {
+    // ---- the wave's operand fragments straight from the two source tensors: lane (l31, half) of k-half s of slice sl needs
+    //      the 16-byte pieces (2 s + half) [hi] and (4 + 2 s + half) [lo] of its pixel's 128-byte channel-slice record — the
+    //      split32 format IS the fragment layout.  Rows past the end read zeros (out-of-range buffer offsets).
+    constexpr int CS1 = (CW - CW2) / 32;
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t1), 0, p.t1_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t1b), 0, p.t1b_bytes, 0x00020000);
+    // chunk 0's filters first: their L2 round trip runs under the fragments' HBM round trip (one wait for both)
+    asm volatile("" ::: "memory");
+    dma_w3(0, 0);
+    if constexpr (W1DB && !ROT) dma_w1(0, 0);
+    asm volatile("" ::: "memory");
+    const long m = pix(wave * 32 + l31);
+    unsigned oa = 0xFFFFFFFFu, ob = 0xFFFFFFFFu;
+    if (m >= 0) {
+      const int ni = (int)(m / hw);
+      const int rem = (int)(m - (long)ni * hw);
+      const int y = rem / p.w, x = rem - y * p.w;
+      oa = (unsigned)m * (unsigned)p.t1_ld * 4u;
+      ob = ((unsigned)(ni * p.hb + y * p.sb) * (unsigned)p.wb + (unsigned)(x * p.sb)) * (unsigned)p.t1b_ld * 4u;
+    }
+#pragma unroll
+    for (int sl = 0; sl < CS; ++sl)
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        const bool first = sl < CS1;                                 // compile-time after unrolling
+        const unsigned base = first ? oa : ob;
+        const unsigned off = (unsigned)((first ? sl : sl - CS1) * 128);
+        const unsigned vh = base == 0xFFFFFFFFu ? base : base + off + (unsigned)((2 * sk + half) << 4);
+        const unsigned vl = base == 0xFFFFFFFFu ? base : base + off + (unsigned)((4 + 2 * sk + half) << 4);
+        ah[sl][sk] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(first ? rs_a : rs_b, (int)vh, 0, 0));
+        al[sl][sk] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(first ? rs_a : rs_b, (int)vl, 0, 0));
+      }
+    // all of them landed HERE, outside the chunk loop: a fragment the compiler still believed in flight at the loop header
+    // would get a conservative vmcnt wait in front of its first use in EVERY chunk, draining the loop's counted pipeline
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int sl = 0; sl < CS; ++sl)
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) asm volatile("" : "+v"(ah[sl][sk]), "+v"(al[sl][sk]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if constexpr (ALIAS) {                                         // T2 shares LDS with the chunk buffers: fragments first, filters after
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -583,8 +636,10 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     __builtin_amdgcn_sched_barrier(0);
   }
   asm volatile("" ::: "memory");
-  dma_w3(0, 0);
-  if constexpr (W1DB && !ROT) dma_w1(0, 0);
+  if constexpr (!DIRECT) {
+    dma_w3(0, 0);
+    if constexpr (W1DB && !ROT) dma_w1(0, 0);
+  }
   asm volatile("" ::: "memory");
   if (nch > 0) load_res(0);
   __builtin_amdgcn_sched_barrier(0);
@@ -612,7 +667,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
     // ---- phase 2 operands: T2 (A: the wave's own 32 rows, the same for every chunk — read once, kept in registers) and
     //      filter group j (B), all K slices
     const char* b2base = lds + W3B_OFF + (j & 1) * W3CH + l31 * ROWB;
-    if constexpr (!ALIAS) {
+    if constexpr (!ALIAS && !DIRECT) {
       if (j == 0) read_a2();
     }
     constexpr int BG = (CS <= 4 && (HAS_C2 || WPS == 1)) ? CS : 2;   // slices of filter fragments in flight (all of them up to CS = 4, registers permitting)
@@ -886,12 +941,12 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2) * BMT
   }
 }
 
-template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false>
+template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false, int CW2 = 0>
 int launch(const ChainK& k, hipStream_t s) {
-  constexpr int LDS = lds_bytes(BMT, CW, CN, HAS_C2);
-  FCP_LDS_OPT_IN((&bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH>), LDS);
+  constexpr int LDS = lds_bytes(BMT, CW, CN, HAS_C2, CW2 > 0);
+  FCP_LDS_OPT_IN((&bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH, CW2>), LDS);
   const int tiles = PATCH ? k.n * fcp_cdiv(k.h, BMT / 16) * ((k.w + 15) >> 4) : fcp_cdiv(k.M, BMT);
-  hipLaunchKernelGGL((bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH>), dim3(tiles), dim3(2 * BMT), LDS, s, k);
+  hipLaunchKernelGGL((bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH, CW2>), dim3(tiles), dim3(2 * BMT), LDS, s, k);
   FCP_LAUNCH_OK();
   return 0;
 }
@@ -911,7 +966,9 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
                     : (!has_c2 && d->c == 128 && d->nout == 512 && d->res && d->cn == 128) ? 3
                     : (!has_c2 && d->c == 128 && d->nout == 256 && !d->res && d->cn == 64) ? 4
                     : (!has_c2 && d->c == 256 && d->nout == 1024 && d->res && d->cn == 256) ? 5
-                    : (!has_c2 && d->c == 128 && d->nout == 512 && d->res && d->cn == 256) ? 6 : 0;
+                    : (!has_c2 && d->c == 128 && d->nout == 512 && d->res && d->cn == 256) ? 6
+                    : (!has_c2 && d->t1b && d->c == 384 && d->cb == 256 && d->nout == 512 && !d->res && d->cn == 128) ? 7 : 0;
+  FCP_REQUIRE(variant == 7 || !d->t1b, "chain: a second source (t1b) exists for the two-source pair form only (c 384 = 128 + 256, nout 512, cn 128)");
   FCP_REQUIRE(variant != 0, "chain: unsupported shape (c %d, conv2 %d, nout %d, residual %d, cn %d)", d->c, (int)has_c2, d->nout,
               d->res != nullptr, d->cn);
   FCP_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "chain: bad sizes");
@@ -920,7 +977,7 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   auto aligned = [](const void* p, int ld) { return ((uintptr_t)p & 127) == 0 && ld % 32 == 0; };
   FCP_REQUIRE(aligned(d->t1, d->t1_ld) && (!d->res || aligned(d->res, d->res_ld)) && aligned(d->out, d->out_ld) && aligned(d->t1n, d->t1n_ld),
               "chain: tensors are split32 views: 128-byte aligned, channel stride a multiple of 32");
-  FCP_REQUIRE(d->t1_ld >= d->c && (!d->res || d->res_ld >= d->nout) && d->out_ld >= d->nout && d->t1n_ld >= d->cn, "chain: channel strides too small");
+  FCP_REQUIRE(d->t1_ld >= d->c - (d->t1b ? d->cb : 0) && (!d->res || d->res_ld >= d->nout) && d->out_ld >= d->nout && d->t1n_ld >= d->cn, "chain: channel strides too small");
   const unsigned long t1_bytes = (unsigned long)M * d->t1_ld * 4ul;
   FCP_REQUIRE(t1_bytes < 0xFFFFFFF0ul, "chain: t1 must be below 4 GiB");
   ChainK k;
@@ -936,6 +993,15 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   k.n = d->n; k.h = d->h; k.w = d->w; k.M = (int)M;
   static const int nt_env = getenv("FCP_NT_STORE") ? atoi(getenv("FCP_NT_STORE")) : 1;
   k.nt_store = nt_env;
+  k.t1b = nullptr; k.t1b_bytes = 0; k.t1b_ld = 0; k.hb = 0; k.wb = 0; k.sb = 1;
+  if (d->t1b) {
+    FCP_REQUIRE(aligned(d->t1b, d->t1b_ld) && d->t1b_ld >= d->cb && d->t1b_stride >= 1 && d->t1b_h > 0 && d->t1b_w > 0 &&
+                (long)(d->h - 1) * d->t1b_stride < d->t1b_h && (long)(d->w - 1) * d->t1b_stride < d->t1b_w,
+                "chain: t1b must be a split32 view whose (h, w) grid covers the output grid at t1b_stride");
+    const unsigned long tb = (unsigned long)d->n * d->t1b_h * d->t1b_w * d->t1b_ld * 4ul;
+    FCP_REQUIRE(tb < 0xFFFFFFF0ul, "chain: t1b must be below 4 GiB");
+    k.t1b = d->t1b; k.t1b_bytes = (unsigned)tb; k.t1b_ld = d->t1b_ld; k.hb = d->t1b_h; k.wb = d->t1b_w; k.sb = d->t1b_stride;
+  }
   k.out_even = (d->flags & FCP_CHAIN_OUT_EVEN_ONLY) ? 1 : 0;
   FCP_REQUIRE(!k.out_even || d->tile_m == 16 || d->tile_m == 32, "chain: FCP_CHAIN_OUT_EVEN_ONLY needs a patch form (tile_m = 16 | 32)");
   hipStream_t s = (hipStream_t)stream;
@@ -954,6 +1020,7 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
     case 3: return big ? launch<128, 128, 512, false, true, 256>(k, s) : launch<128, 128, 512, false, true, 128>(k, s);
     case 5: return launch<256, 256, 1024, false, true, 128>(k, s);
     case 6: return launch<256, 128, 512, false, true, 128>(k, s);     // CN = 256: 128 accumulator registers, one wave per SIMD only
+    case 7: return launch<128, 384, 512, false, false, 128, false, 256>(k, s);   // [conv2 out 128 | x(::2, ::2) 256] -> 512 -> 128
     default: return big ? launch<64, 128, 256, false, false, 256>(k, s) : launch<64, 128, 256, false, false, 128>(k, s);
   }
 }

@@ -131,10 +131,12 @@ std::tuple<Tensor, Tensor> bottleneck_chain(const Tensor& t1, int64_t t1_c0, con
                                             const c10::optional<Tensor>& w2, const c10::optional<Tensor>& ws2,
                                             const c10::optional<Tensor>& b2, const Tensor& w3, const Tensor& ws3,
                                             const Tensor& b3, const Tensor& w1n, const Tensor& ws1n, const Tensor& b1n,
-                                            int64_t c, int64_t nout, int64_t cn, int64_t tile_m, int64_t flags) {
+                                            int64_t c, int64_t nout, int64_t cn, int64_t tile_m, int64_t flags,
+                                            const c10::optional<Tensor>& t1b, int64_t t1b_c0, int64_t cb, int64_t t1b_stride) {
   dev(t1, "t1", at::kFloat);
   FCP_DEVICE_GUARD(t1);
-  TORCH_CHECK(t1.dim() == 4 && t1_c0 + c <= t1.size(3), "t1 (n,h,w,>=c) split32 buffer");
+  const bool two = t1b.has_value() && t1b->defined();              // two-source pair: the trailing cb input channels come from t1b
+  TORCH_CHECK(t1.dim() == 4 && t1_c0 + c - (two ? cb : 0) <= t1.size(3), "t1 (n,h,w,>=c) split32 buffer");
   const bool has_res = res.has_value() && res->defined();
   if (has_res) {
     dev(*res, "res", at::kFloat);
@@ -152,6 +154,12 @@ std::tuple<Tensor, Tensor> bottleneck_chain(const Tensor& t1, int64_t t1_c0, con
   d.w1n = w1n.data_ptr(); d.ws1n = dev(ws1n, "ws1n", at::kFloat).data_ptr<float>(); d.b1n = dev(b1n, "b1n", at::kFloat).data_ptr<float>();
   d.n = (int)t1.size(0); d.h = (int)t1.size(1); d.w = (int)t1.size(2); d.c = (int)c; d.cn = (int)cn; d.nout = (int)nout;
   d.t1_ld = (int)t1.size(3); d.out_ld = (int)nout; d.t1n_ld = (int)cn; d.tile_m = (int)tile_m; d.flags = (int)flags;
+  if (two) {
+    dev(*t1b, "t1b", at::kFloat);
+    TORCH_CHECK(t1b->dim() == 4 && t1b->size(0) == t1.size(0) && t1b_c0 + cb <= t1b->size(3), "t1b (n,hb,wb,>=cb) split32 buffer");
+    d.t1b = t1b->data_ptr<float>() + t1b_c0; d.cb = (int)cb; d.t1b_ld = (int)t1b->size(3);
+    d.t1b_h = (int)t1b->size(1); d.t1b_w = (int)t1b->size(2); d.t1b_stride = (int)t1b_stride;
+  }
   ok(fcp_bottleneck_chain_f16x3(&d, cur_stream()), "fcp::bottleneck_chain");
   return {out, t1n};
 }
@@ -300,7 +308,8 @@ TORCH_LIBRARY(fcp, m) {
         "bool cin4, int tile_m, int tile_n, Tensor? x2, int x2_c0, int cin2, int x2_stride, int flags, int cu_budget=0, int band_top=0, "
         "int band_bottom=0) -> ()");
   m.def("bottleneck_chain(Tensor t1, int t1_c0, Tensor? res, int res_c0, Tensor? w2, Tensor? ws2, Tensor? b2, Tensor w3, Tensor ws3, "
-        "Tensor b3, Tensor w1n, Tensor ws1n, Tensor b1n, int c, int nout, int cn, int tile_m=0, int flags=0) -> (Tensor, Tensor)");
+        "Tensor b3, Tensor w1n, Tensor ws1n, Tensor b1n, int c, int nout, int cn, int tile_m=0, int flags=0, Tensor? t1b=None, "
+        "int t1b_c0=0, int cb=0, int t1b_stride=1) -> (Tensor, Tensor)");
   m.def("retina_decode(Tensor head0, Tensor head1, Tensor head2, int img_h, int img_w, float vis, float var0, float var1) "
         "-> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("nms_select(Tensor cand_score, Tensor cand_box, Tensor cand_count, float nms_threshold, int strategy) "

@@ -595,17 +595,21 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     return out
 
 
-def chain_supported(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, residual: bool = True) -> bool:
+def chain_supported(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, residual: bool = True, cb: int = 0) -> bool:
     """Shapes ``fcp_bottleneck_chain_f16x3`` covers, all packed for the fp16x3 path with folded-BN bias:
     * with conv2: 64-wide bottleneck (3x3 64->64 / 1, 1x1 64->256 + residual), next conv1 1x1 256 -> 64 | 128;
     * pair (``pc2`` None): 1x1 128->512 + residual, next conv1 512->128 | 256  (layer-2 identity blocks; the last one
       with layer3.0.conv1),
       1x1 256->1024 + residual, next conv1 1024->256  (layer-3 identity blocks), or
-      1x1 128->256 without residual, next conv1 256->64  (layer1.0's conv3 + downsample K-concat, layer1.1.conv1)."""
+      1x1 128->256 without residual, next conv1 256->64  (layer1.0's conv3 + downsample K-concat, layer1.1.conv1);
+    * two-source pair (``cb`` = channels of the second source): 1x1 (128 + 256)->512 without residual, next conv1 512->128
+      (layer2.0's conv3 + stride-2 downsample over [conv2 out | x(::2, ::2)], layer2.1.conv1)."""
     convs = [pc for pc in (pc2, pc3, pc1n) if pc is not None]
     if not all(pc.precision == 1 and pc.bias is not None and not pc.cin4 for pc in convs):
         return False
     one = lambda pc, cin, cout: (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad) == (cin, cout, 1, 1, 1, 0)
+    if cb:
+        return pc2 is None and not residual and cb == 256 and one(pc3, 384, 512) and one(pc1n, 512, 128) and CHAIN_TWO_SOURCE
     if pc2 is not None:
         return ((pc2.cin, pc2.cout, pc2.kh, pc2.kw, pc2.stride, pc2.pad) == (64, 64, 3, 3, 1, 1) and residual
                 and one(pc3, 64, 256) and (one(pc1n, 256, 64) or one(pc1n, 256, 128)))
@@ -622,18 +626,25 @@ CHAIN_TILE_M = int(os.environ.get("FCP_CHAIN_TILE_M", "0"))   # 0 / 128: 4-wave 
 CHAIN_PATCH = os.environ.get("FCP_CHAIN_PATCH", "1") != "0"
 # ... and a block whose output only a stride-2 consumer reads stores the even pixels only (bottleneck_chain(out_even_only=True))
 CHAIN_SPARSE_OUT = os.environ.get("FCP_CHAIN_SPARSE_OUT", "1") != "0"
+# layer2.0's two-source conv3 (+ downsample) and layer2.1.conv1 as one pair launch (A/B switch: 0 = the two conv launches)
+CHAIN_TWO_SOURCE = os.environ.get("FCP_CHAIN_TWO_SOURCE", "1") != "0"
 
 
 def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, t1: Act, res: Act | None,
-                     out: Act | None = None, t1n: Act | None = None, tile_m: int | None = None, out_even_only: bool = False):
+                     out: Act | None = None, t1n: Act | None = None, tile_m: int | None = None, out_even_only: bool = False,
+                     t1b: Act | None = None, t1b_stride: int = 1):
     """One launch for  out = relu(conv3(relu(conv2(t1))) [+ res]),  t1n = relu(conv1n(out))  (BatchNorm folded): conv2 /
     conv3 of a bottleneck and conv1 of the next block; ``pc2`` None: the pair forms (no conv2, see ``chain_supported``).
     Bit-identical to the separate ``conv`` calls.  Returns (out, t1n), both split32.  ``out_even_only`` (conv2 forms on patch
     tiles): ``out`` is only stored at pixels with even y and even x — for a block whose output nothing but a stride-2 consumer
     reads (the other three quarters of the tensor are never written nor read; ``t1n`` is complete).  Ignored, i.e. a full
-    ``out``, where the patch form is not in use or a ``RangeMonitor`` wants to see the whole tensor."""
-    assert chain_supported(pc2, pc3, pc1n, res is not None), "bottleneck_chain: unsupported shapes"
-    assert t1.fmt == 1 and t1.c == pc3.cin and (res is None or (res.fmt == 1 and res.c == pc3.cout))
+    ``out``, where the patch form is not in use or a ``RangeMonitor`` wants to see the whole tensor.  ``t1b`` (two-source
+    pair): the trailing ``t1b.c`` input channels of conv3 are read from ``t1b`` at ``(y * t1b_stride, x * t1b_stride)`` —
+    what ``conv(..., x2=, x2_stride=)`` does for the stand-alone two-source conv."""
+    cb = t1b.c if t1b is not None else 0
+    assert chain_supported(pc2, pc3, pc1n, res is not None, cb), "bottleneck_chain: unsupported shapes"
+    assert t1.fmt == 1 and t1.c + cb == pc3.cin and (res is None or (res.fmt == 1 and res.c == pc3.cout))
+    assert t1b is None or (t1b.fmt == 1 and t1b.n == t1.n and (t1.h - 1) * t1b_stride < t1b.h and (t1.w - 1) * t1b_stride < t1b.w)
     assert res is None or (t1.n, t1.h, t1.w) == (res.n, res.h, res.w)
     dev = t1.buf.device
     m = t1.n * t1.h * t1.w
@@ -650,7 +661,8 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
         # FCP_BOUNDARY=torch: the registered custom op allocates and returns both tensors
         o, t = T.load().bottleneck_chain(t1.buf, t1.c0, None if res is None else res.buf, 0 if res is None else res.c0,
                                          opt(pc2, "w"), opt(pc2, "wscale"), opt(pc2, "bias"), pc3.w, pc3.wscale, pc3.bias,
-                                         pc1n.w, pc1n.wscale, pc1n.bias, pc3.cin, pc3.cout, pc1n.cout, tile_m, flags)
+                                         pc1n.w, pc1n.wscale, pc1n.bias, pc3.cin, pc3.cout, pc1n.cout, tile_m, flags,
+                                         None if t1b is None else t1b.buf, 0 if t1b is None else t1b.c0, cb, int(t1b_stride))
         out, t1n = Act(o, fmt=1), Act(t, fmt=1)
     else:
         if out is None:
@@ -664,9 +676,11 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
         d.w2, d.ws2, d.b2 = N.ptr(opt(pc2, "w")), N.ptr(opt(pc2, "wscale")), N.ptr(opt(pc2, "bias"))
         d.w3, d.ws3, d.b3 = N.ptr(pc3.w), N.ptr(pc3.wscale), N.ptr(pc3.bias)
         d.w1n, d.ws1n, d.b1n = N.ptr(pc1n.w), N.ptr(pc1n.wscale), N.ptr(pc1n.bias)
-        d.n, d.h, d.w, d.c, d.cn, d.nout = t1.n, t1.h, t1.w, pc3.cin, pc1n.cout, pc3.cout
+        d.n, d.h, d.w, d.c, d.cn, d.nout = t1.n, t1.h, t1.w, pc3.cin, pc1n.cout, pc3.cout    # c: all of conv3's input channels
         d.t1_ld, d.res_ld, d.out_ld, d.t1n_ld = t1.ld, (res.ld if res is not None else 0), out.ld, t1n.ld
         d.tile_m, d.flags = tile_m, flags
+        if t1b is not None:
+            d.t1b, d.cb, d.t1b_ld, d.t1b_h, d.t1b_w, d.t1b_stride = t1b.ptr(), cb, t1b.ld, t1b.h, t1b.w, t1b_stride
         N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
     if timing is not None:
         e1.record()
@@ -674,7 +688,7 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
         byts = 4 * (m * (c + (nout if not flags else nout // 4) + (nout if res is not None else 0) + cn) + (0 if pc2 is None else 9 * c * c)
                     + c * nout + nout * cn)
         timing.append((e0, e1, flops, f"chain {'3x3 ' if pc2 is not None else ''}{c}->{nout}->{cn} @{t1.h}x{t1.w}"
-                       f"{' +res' if res is not None else ''}{' out@even' if flags else ''}", byts))
+                       f"{' +res' if res is not None else ''}{' out@even' if flags else ''}{' two-source' if t1b is not None else ''}", byts))
     if ConvStats.enabled:
         ConvStats.flops += flops
         ConvStats.launches += 1

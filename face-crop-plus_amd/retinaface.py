@@ -221,6 +221,12 @@ class RetinaFace:
                 continue
             if "c3ds" in blk:
                 o = E.conv(blk["c2"], o, act_slope=0.0, out_fmt=f)
+                if (chain and not blk["feat"] and nxt is not None
+                        and E.chain_supported(None, blk["c3ds"], nxt["c1"], residual=False, cb=x.c)):
+                    # layer2.0: conv3 + the 1x1 / 2 downsample over the two sources [conv2 out | x(::2, ::2)] AND layer2.1's
+                    # conv1 in one launch: the 512-channel block output is written once and not read back by a conv1 launch
+                    x, pre = E.bottleneck_chain(None, blk["c3ds"], nxt["c1"], o, None, t1b=x, t1b_stride=blk["c2"].stride)
+                    continue
                 x = E.conv(blk["c3ds"], o, act_slope=0.0, out_fmt=f, x2=x, x2_stride=blk["c2"].stride)
                 if blk["feat"]:
                     feats.append(x)

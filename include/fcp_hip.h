@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 14
+#define FCP_ABI_VERSION 15
 
 typedef void* fcp_stream_t; /* hipStream_t */
 
@@ -155,6 +155,12 @@ int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);
  *   c = 256, nout = 1024, res != NULL, cn = 256   conv3 of a layer-3 identity block + conv1 of the next block
  *   c = 128, nout = 256,  res == NULL, cn = 64    layer1.0: conv3 + downsample as one K-concatenated 1x1 conv over
  *                                                 [conv2 out | pooled stem] (engine.py packs it so), + layer1.1.conv1
+ *   c = 384, nout = 512,  res == NULL, cn = 128,  t1b != NULL, cb = 256 (round 5)
+ *                                                 layer2.0: conv3 + the 1x1 / 2 downsample as one K-concatenated conv over the TWO
+ *                                                 sources [conv2 out (t1: 128 ch) | x(::2, ::2) (t1b: 256 ch at twice the
+ *                                                 resolution)], + layer2.1.conv1: the 512-channel block output is written once
+ *                                                 and not read back by a separate conv1 launch.  The operand fragments are
+ *                                                 loaded straight from the two tensors (no LDS tile).
  * ------------------------------------------------------------------------ */
 typedef struct fcp_chain_desc {
   const float* t1;    /* conv2's input: c channels */
@@ -164,6 +170,9 @@ typedef struct fcp_chain_desc {
   float* out;         /* 4c channels */
   const void* w1n; const float* ws1n; const float* b1n;
   float* t1n;         /* cn channels */
+  const float* t1b;   /* two-source pair form: the trailing cb of conv3's c input channels come from this split32 tensor
+                       * (n, t1b_h, t1b_w, t1b_ld), sampled at (y * t1b_stride, x * t1b_stride); t1 holds the leading c - cb.
+                       * NULL: one source */
   int32_t n, h, w, c, cn;
   int32_t t1_ld, res_ld, out_ld, t1n_ld;
   int32_t nout;       /* conv3's filters: 4c with conv2; see the pair forms below */
@@ -177,6 +186,7 @@ typedef struct fcp_chain_desc {
                        * layer1.2: the next block's 1x1 / 2 downsample reads `out`, its conv1 is t1n, computed here): three
                        * quarters of the tensor are never written nor read.  The other pixels of the buffer keep whatever
                        * they held.  t1n is complete either way. */
+  int32_t cb, t1b_ld, t1b_h, t1b_w, t1b_stride;   /* geometry of t1b (all 0 without it) */
 } fcp_chain_desc;
 #define FCP_CHAIN_OUT_EVEN_ONLY 1
 

@@ -165,3 +165,61 @@ def test_chain_out_even_only(n, h, w, device):
     a = E.conv(pcd, o, act_slope=0.0, out_fmt=1, x2=full, x2_stride=2)
     b = E.conv(pcd, o, act_slope=0.0, out_fmt=1, x2=out, x2_stride=2)
     assert torch.equal(a.buf, b.buf)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 20, 24), (1, 7, 5), (3, 33, 41), (2, 80, 80), (1, 1, 1)])
+def test_two_source_pair_equals_the_two_convs(n, h, w, device):
+    """Round 5: layer2.0's conv3 + stride-2 downsample (one 1x1 conv over the K concatenation of TWO tensors, [conv2 out |
+    x(::2, ::2)]) and layer2.1's conv1 as ONE pair launch whose operand fragments are loaded straight from the two tensors
+    (no LDS tile): bit-identical to the two-source conv followed by the conv1 launch, odd sizes (x has 2h or 2h - 1 rows) and
+    ragged tiles included; and both match a torch fp32 reference of bn3(conv3(o)) + bn_d(down(x)) -> relu -> conv1 -> relu."""
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(n * 100 + h)
+    hx, wx = 2 * h - (h % 2), 2 * w - (w % 3 == 0)                      # the strided grid covers (h, w) either way
+    o = F.relu(torch.randn(n, 128, h, w, generator=g))
+    x = F.relu(torch.randn(n, 256, hx, wx, generator=g))
+    w3 = torch.randn(512, 128, 1, 1, generator=g) * (2 / 128) ** 0.5
+    wd = torch.randn(512, 256, 1, 1, generator=g) * (2 / 256) ** 0.5
+    w1 = torch.randn(128, 512, 1, 1, generator=g) * (2 / 512) ** 0.5
+    bn3, bnd, bn1 = _bn(512, g), _bn(512, g), _bn(128, g)
+    with E.default_precision("f16x3"):
+        (w3f, b3f), (wdf, bdf) = E.fold_bn(w3.numpy(), {k: v.numpy() for k, v in bn3.items()}, None), \
+            E.fold_bn(wd.numpy(), {k: v.numpy() for k, v in bnd.items()}, None)
+        pc3 = E.pack_conv(np.concatenate([w3f, wdf], 1), b3f + bdf, None, 1, 0, device)      # retinaface.py::_pack "c3ds"
+        pc1 = E.pack_conv(w1, None, bn1, 1, 0, device)
+    assert E.chain_supported(None, pc3, pc1, residual=False, cb=256)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(device)
+    oa, xa = E.f32_to_split32(E.Act(nhwc(o))), E.f32_to_split32(E.Act(nhwc(x)))
+    ref_out = E.conv(pc3, oa, act_slope=0.0, out_fmt=1, x2=xa, x2_stride=2)
+    ref_t1n = E.conv(pc1, ref_out, act_slope=0.0, out_fmt=1)
+    out, t1n = E.bottleneck_chain(None, pc3, pc1, oa, None, t1b=xa, t1b_stride=2)
+    torch.cuda.synchronize()
+    assert torch.equal(out.buf, ref_out.buf), "fused two-source conv3 output differs from the stand-alone kernel"
+    assert torch.equal(t1n.buf, ref_t1n.buf), "fused next-conv1 output differs from the stand-alone kernel"
+    again = E.bottleneck_chain(None, pc3, pc1, oa, None, t1b=xa, t1b_stride=2)
+    assert torch.equal(again[0].buf, out.buf) and torch.equal(again[1].buf, t1n.buf)
+    r3 = F.relu(_ref_bn(F.conv2d(o, w3), bn3) + _ref_bn(F.conv2d(x, wd, None, 2), bnd)[:, :, :h, :w])
+    r1 = F.relu(_ref_bn(F.conv2d(r3, w1), bn1))
+    for got, ref in ((out, r3), (t1n, r1)):
+        err = (got.nchw().cpu() - ref).abs().max().item()
+        assert err <= 3e-5 * float(ref.abs().max()) + 1e-6, err
+    # channel-slice views of wider buffers on both sources
+    wide_o, wide_x = E.Act.empty(n, h, w, 192, device, 1), E.Act.empty(n, hx, wx, 320, device, 1)
+    wide_o.buf.copy_(torch.randn_like(wide_o.buf)); wide_x.buf.copy_(torch.randn_like(wide_x.buf))
+    wide_o.buf[..., 64:].copy_(oa.buf); wide_x.buf[..., 32:288].copy_(xa.buf)
+    o2, t2 = E.bottleneck_chain(None, pc3, pc1, wide_o.slice(64, 128), None, t1b=wide_x.slice(32, 256), t1b_stride=2)
+    assert torch.equal(o2.buf, out.buf) and torch.equal(t2.buf, t1n.buf)
+    # a second source whose grid does not cover the output grid is rejected by the library
+    from face_crop_plus_amd import _native as N
+    import ctypes as C
+    small = E.Act.empty(n, max(1, (h - 1) * 2), wx, 256, device, 1)      # one row short: (h - 1) * 2 is not < its height
+    d = N.ChainDesc()
+    d.t1, d.out, d.t1n, d.t1b = oa.ptr(), out.ptr(), t1n.ptr(), small.ptr()
+    d.w3, d.ws3, d.b3 = N.ptr(pc3.w), N.ptr(pc3.wscale), N.ptr(pc3.bias)
+    d.w1n, d.ws1n, d.b1n = N.ptr(pc1.w), N.ptr(pc1.wscale), N.ptr(pc1.bias)
+    d.n, d.h, d.w, d.c, d.cn, d.nout = n, h, w, 384, 128, 512
+    d.t1_ld, d.out_ld, d.t1n_ld = 128, 512, 128
+    d.cb, d.t1b_ld, d.t1b_h, d.t1b_w, d.t1b_stride = 256, 256, small.h, small.w, 2
+    if h > 1:
+        with pytest.raises(RuntimeError, match="t1b"):
+            N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
