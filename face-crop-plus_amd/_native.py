@@ -62,6 +62,7 @@ SIGNATURES = {
     "fcp_maxpool3x3s2_split32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "fcp_stem7x7s2_relu_pool_u8": [_P, _I, _I, _I, C.POINTER(C.c_int32), _P, _P, _P, _P, _I, _I, _P],
     "fcp_stem7x7s2_relu_pool_conv1_u8": [_P, _I, _I, _I, C.POINTER(C.c_int32), _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
+    "fcp_stem7x7s2_relu_pool_f32": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     "fcp_f32_to_split32": [_P, _P, _L, _I, _P],
     "fcp_split32_to_f32": [_P, _P, _L, _I, _P],
     "fcp_absmax_nhwc": [_P, _L, _I, _I, _I, _P, _P],

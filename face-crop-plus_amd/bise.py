@@ -13,6 +13,7 @@ the device.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -39,6 +40,8 @@ class BiSeNet:
         self.device = None
         self._p = None
         self.precision = 0
+        # fp16x3 path: conv1 + bn1 + relu + maxpool of the ResNet-18 stem in one launch (A/B switch: FCP_BISE_FUSED_STEM=0)
+        self.fused_stem = os.environ.get("FCP_BISE_FUSED_STEM", "1") != "0"
 
     def load(self, device="cuda:0", weights=None, precision=None):
         device = torch.device(device)
@@ -95,6 +98,9 @@ class BiSeNet:
     def _pack(sd, dev):
         pc, bn = E.pack_conv, E.bn_of
         p = {"stem": pc(sd["cp.resnet.conv1.weight"], None, bn(sd, "cp.resnet.bn1"), 2, 3, dev)}
+        if E.DEFAULT_PRECISION == 1:
+            # normalised fp32 face -> conv1 + bn1 + relu + maxpool in one launch (hi / lo planes staged in LDS)
+            p["stem_fused"] = E.pack_stem_fused(sd["cp.resnet.conv1.weight"], bn(sd, "cp.resnet.bn1"), dev)
         blocks = []
         for li in (1, 2, 3, 4):
             for b in (0, 1):
@@ -165,7 +171,10 @@ class BiSeNet:
         # read by the small attention kernels (avg-pool / scale-add) stay fp32
         f = 1 if self.precision == 1 else 0
         sp = (lambda a: E.f32_to_split32(a)) if f else (lambda a: a)
-        x = E.maxpool3x3s2(E.conv(p["stem"], x4, act_slope=0.0, out_fmt=f))
+        if f and self.fused_stem and "stem_fused" in p:
+            x = E.stem_relu_pool_f32(p["stem_fused"], x4, out_fmt=1)        # the 256 x 256 x 64 stem map never reaches HBM
+        else:
+            x = E.maxpool3x3s2(E.conv(p["stem"], x4, act_slope=0.0, out_fmt=f))
         feats = {}
         fcat = None
         for blk in p["blocks"]:

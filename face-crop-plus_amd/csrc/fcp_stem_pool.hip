@@ -73,6 +73,7 @@ struct StemGeo {
 
 struct StemParams {
   const uint8_t* img;
+  const float* imgf;       // F32IN: fp32 NHWC4 input (n, h, w, 4), already normalised (BiSeNet, bise.py:387-393); channel 3 is ignored
   const uint32_t* wfrag;   // [2 column tiles][11 k-steps][hi, lo][64 lanes][4 dwords]
   const float* bias;
   const float* wscale;
@@ -99,14 +100,21 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <bool HAS_C1, int PW_>
+// F32IN (round 5; BiSeNet's ResNet-18 stem, _layers.py:241-247 of the reference): the input is an fp32 NHWC4 tensor instead of
+// bytes minus an integer mean, so the activation has a lo part: the patch is staged as TWO binary16 planes (hi = x rounded toward
+// zero, lo = x - hi, the split of every other fp16x3 kernel) and a k-step is three matrix instructions (al*wh + ah*wl + ah*wh)
+// instead of two.  Everything else — patch walk, K order (kh, kw * 3 + c), staging, separable max-pool, scale / bias / ReLU on
+// the pooled pixels — is the same code.
+template <bool HAS_C1, int PW_, bool F32IN = false>
 __global__ void __launch_bounds__(StemGeo<PW_>::NT, StemGeo<PW_>::WGS) stem_pool_kernel(const StemParams p) {
+  static_assert(!(HAS_C1 && F32IN), "the fp32-input stem has no conv1 tail");
   using G = StemGeo<PW_>;
   constexpr int PW = G::PW, SW = G::SW, NSTEM = G::NSTEM, NTILES = G::NTILES, IWB = G::IWB, IPITCH = G::IPITCH;
   constexpr int IN_ELEMS = G::IN_ELEMS, NT = G::NT, NGRP = G::NGRP, TPR = G::TPR, NLOAD = G::NLOAD, C1ROWS = G::C1ROWS;
   constexpr int KPG = NTILES / NGRP;                                // row tiles per wave: 3
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ __attribute__((aligned(16))) _Float16 inh[IN_ELEMS];   // (x - mean) as binary16: exact integers
+  __shared__ __attribute__((aligned(16))) _Float16 inh[IN_ELEMS];   // (x - mean) as binary16: exact integers (F32IN: the hi parts)
+  __shared__ __attribute__((aligned(16))) _Float16 inl[F32IN ? IN_ELEMS : 8];   // F32IN: the lo parts
   float* stage = smem;
   char* c1in = reinterpret_cast<char*>(smem + NSTEM * SPITCH);      // HAS_C1: conv1's operand image (split32 rows, swizzled)
 
@@ -147,7 +155,8 @@ __global__ void __launch_bounds__(StemGeo<PW_>::NT, StemGeo<PW_>::WGS) stem_pool
   _Float16* const fdst = inh + min(frow, IH - 1) * IPITCH + fc0;
   // fetch(): branch-free byte loads from clamped (always valid) addresses, nothing consumed before commit(), so
   // all of them are in flight under the MFMAs of the current patch
-  uint8_t pre[NLOAD];
+  uint8_t pre[F32IN ? 1 : NLOAD];
+  float pref[F32IN ? NLOAD : 1];
   unsigned pre_ok = 0u;
   auto fetch = [&](int patch) {
     const int pxi = patch % p.tiles_x;
@@ -158,24 +167,41 @@ __global__ void __launch_bounds__(StemGeo<PW_>::NT, StemGeo<PW_>::WGS) stem_pool
     const bool rowok = (unsigned)y < (unsigned)p.h && frow < IH;
     const int yc = min(max(y, 0), p.h - 1);
     const uint8_t* base = p.img + ((long)ni * p.h + yc) * p.w * 3 + fch;
+    const float* basef = p.imgf + ((long)ni * p.h + yc) * p.w * 4 + fch;
     pre_ok = 0u;
 #pragma unroll
     for (int j = 0; j < NLOAD; ++j) {
       const int x = ix0 + fx0 + (TPR / 3) * j;
       pre_ok |= (rowok && (unsigned)x < (unsigned)p.w) ? (1u << j) : 0u;
-      pre[j] = base[(unsigned)(min(max(x, 0), p.w - 1) * 3)];
+      if constexpr (F32IN) pref[j] = basef[(unsigned)(min(max(x, 0), p.w - 1) * 4)];
+      else pre[j] = base[(unsigned)(min(max(x, 0), p.w - 1) * 3)];
     }
   };
+  _Float16* const fdstl = inl + (F32IN ? min(frow, IH - 1) * IPITCH + fc0 : 0);
   auto commit = [&]() {
     if (frow < IH) {
 #pragma unroll
-      for (int j = 0; j < NLOAD; ++j)       // x - mean, or 0 outside the image (the conv's zero padding)
-        if (fc0 + TPR * j < IWB) fdst[TPR * j] = (_Float16)(float)(((pre_ok >> j) & 1u) ? (int)pre[j] - fmean : 0);
+      for (int j = 0; j < NLOAD; ++j) {     // x - mean, or 0 outside the image (the conv's zero padding)
+        if (fc0 + TPR * j < IWB) {
+          if constexpr (F32IN) {            // hi = x toward zero, lo = x - hi (exact in fp32) toward zero: split8's arithmetic
+            const float v = ((pre_ok >> j) & 1u) ? pref[j] : 0.f;
+            const unsigned hu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v, 0.f));
+            const unsigned lu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fcp_mix_diff<0>(v, hu), 0.f));
+            fdst[TPR * j] = __builtin_bit_cast(_Float16, (unsigned short)(hu & 0xFFFFu));
+            fdstl[TPR * j] = __builtin_bit_cast(_Float16, (unsigned short)(lu & 0xFFFFu));
+          } else {
+            fdst[TPR * j] = (_Float16)(float)(((pre_ok >> j) & 1u) ? (int)pre[j] - fmean : 0);
+          }
+        }
+      }
     }
   };
 
   // zero the spare row / pitch padding once (read by the zero-weight K chunk: must be finite)
-  for (int i = tid; i < IN_ELEMS / 2; i += NT) reinterpret_cast<uint32_t*>(inh)[i] = 0u;
+  for (int i = tid; i < IN_ELEMS / 2; i += NT) {
+    reinterpret_cast<uint32_t*>(inh)[i] = 0u;
+    if constexpr (F32IN) reinterpret_cast<uint32_t*>(inl)[i] = 0u;
+  }
   __syncthreads();
 
   // image-patch byte offset of this lane's stem pixel in each of the wave's row tiles (patch independent)
@@ -213,22 +239,33 @@ __global__ void __launch_bounds__(StemGeo<PW_>::NT, StemGeo<PW_>::WGS) stem_pool
       // K chunk of this lane in step q: filter row ch / 3, part ch % 3 with ch = 2 * q + half; 8 consecutive K values = 8
       // consecutive binary16 of one staged image row (4-byte aligned).  The fragment of step q + 1 is requested before the
       // MFMAs of step q.
-      auto afrag = [&](int q) {
+      auto afrag_of = [&](const _Float16* plane, int q) {
         const int ch = 2 * q + half;
         const int kh = ch / 3, part = ch - kh * 3;
-        const uint32_t* wp = reinterpret_cast<const uint32_t*>(inh + abase + kh * IPITCH + 8 * part);
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>(plane + abase + kh * IPITCH + 8 * part);
         const u32x4_t raw = {wp[0], wp[1], wp[2], wp[3]};
         return __builtin_bit_cast(f16x8, raw);
       };
-      f16x8 a = afrag(0);
+      auto afrag = [&](int q) { return afrag_of(inh, q); };
+      f16x8 a = afrag(0), al = a;
+      if constexpr (F32IN) al = afrag_of(inl, 0);
 #pragma unroll
       for (int q = 0; q < KSTEPS; ++q) {
-        f16x8 an = a;
-        if (q + 1 < KSTEPS) an = afrag(q + 1);
+        f16x8 an = a, aln = al;
+        if (q + 1 < KSTEPS) {
+          an = afrag(q + 1);
+          if constexpr (F32IN) aln = afrag_of(inl, q + 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[q], a, acc, 0, 0, 0);     // filters as the row operand: see below
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q], a, acc, 0, 0, 0);
-        a = an;
+        if constexpr (F32IN) {                                                    // al*wh + ah*wl + ah*wh: the generic kernels' term order
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q], al, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[q], a, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q], a, acc, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[q], a, acc, 0, 0, 0);   // filters as the row operand: see below
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[q], a, acc, 0, 0, 0);
+        }
+        a = an; al = aln;
       }
       // raw accumulators -> stage.  The tile was computed transposed (filters x pixels): a lane holds ONE stem pixel
       // (lane & 31) and filters 8 g + 4 half + 0..3 of its column tile, i.e. four 16-byte staging writes per tile instead
@@ -390,7 +427,7 @@ extern "C" int fcp_stem7x7s2_relu_pool_conv1_u8(const uint8_t* images, int n, in
               "stem: misaligned output view");
   FCP_REQUIRE(((uintptr_t)wfrag & 15) == 0, "stem: filter fragments must be 16-byte aligned");
   for (int c = 0; c < 3; ++c) FCP_REQUIRE(mean_rgb[c] >= 0 && mean_rgb[c] <= 255, "stem: means must be integers in 0..255");
-  StemParams p;
+  StemParams p = {};
   p.img = images; p.wfrag = static_cast<const uint32_t*>(wfrag); p.bias = bias; p.wscale = wscale; p.out = out;
   p.n = n; p.h = h; p.w = w;
   p.hs = (h + 6 - 7) / 2 + 1; p.ws = (w + 6 - 7) / 2 + 1;
@@ -413,6 +450,34 @@ extern "C" int fcp_stem7x7s2_relu_pool_conv1_u8(const uint8_t* images, int n, in
     FCP_LDS_OPT_IN((&stem_pool_kernel<false, FCP_STEM_PW>), lds);
     hipLaunchKernelGGL((stem_pool_kernel<false, FCP_STEM_PW>), dim3(grid), dim3(G::NT), lds, (hipStream_t)stream, p);
   }
+  FCP_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int fcp_stem7x7s2_relu_pool_f32(const float* x4, int n, int h, int w, const void* wfrag, const float* bias,
+                                           const float* wscale, float* out, int out_ld, int out_fmt, fcp_stream_t stream) {
+  FCP_REQUIRE(x4 && wfrag && bias && wscale && out, "stem(f32): null pointer");
+  FCP_REQUIRE(n > 0 && h >= 1 && w >= 1 && (long)h * w * 4 < (1L << 31), "stem(f32): bad image size");
+  FCP_REQUIRE((unsigned)out_fmt <= 1u, "stem(f32): out_fmt must be 0 (fp32) or 1 (split32)");
+  FCP_REQUIRE(out_ld >= 64 && out_ld % (out_fmt ? 32 : 4) == 0 && ((uintptr_t)out & (out_fmt ? 127 : 15)) == 0,
+              "stem(f32): misaligned output view");
+  FCP_REQUIRE(((uintptr_t)wfrag & 15) == 0 && ((uintptr_t)x4 & 15) == 0, "stem(f32): input / filter fragments must be 16-byte aligned");
+  using G = StemGeo<FCP_STEM_PW>;
+  StemParams p = {};
+  p.imgf = x4; p.wfrag = static_cast<const uint32_t*>(wfrag); p.bias = bias; p.wscale = wscale; p.out = out;
+  p.n = n; p.h = h; p.w = w;
+  p.hs = (h + 6 - 7) / 2 + 1; p.ws = (w + 6 - 7) / 2 + 1;
+  p.hp = (p.hs + 2 - 3) / 2 + 1; p.wp = (p.ws + 2 - 3) / 2 + 1;
+  p.out_ld = out_ld; p.out_fmt = out_fmt;
+  p.tiles_y = fcp_cdiv(p.hp, PH); p.tiles_x = fcp_cdiv(p.wp, G::PW);
+  const long np = (long)n * p.tiles_y * p.tiles_x;
+  FCP_REQUIRE(np < (1L << 31) && (long)n * h * w * 4 < (1L << 40), "stem(f32): batch too large");
+  p.npatches = (int)np;
+  const size_t lds = (size_t)G::NSTEM * SPITCH * 4;
+  const int cus = fcp_cu_count() * G::WGS;
+  const int grid = (int)(np < cus ? np : cus);
+  FCP_LDS_OPT_IN((&stem_pool_kernel<false, FCP_STEM_PW, true>), lds);
+  hipLaunchKernelGGL((stem_pool_kernel<false, FCP_STEM_PW, true>), dim3(grid), dim3(G::NT), lds, (hipStream_t)stream, p);
   FCP_LAUNCH_OK();
   return 0;
 }

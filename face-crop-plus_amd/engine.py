@@ -801,6 +801,36 @@ def stem_relu_pool_u8(ps: PackedStem, images_u8: torch.Tensor, out: Act | None =
     return out if conv1 is None else (out, t1)
 
 
+def stem_relu_pool_f32(ps: PackedStem, x4: Act, out: Act | None = None, out_fmt: int = 1) -> Act:
+    """fp32 NHWC4 (n,h,w,4), already normalised -> 7x7 / 2 stem conv (BatchNorm folded) + ReLU + 3x3 / 2 max-pool in one
+    launch (``fcp_stem7x7s2_relu_pool_f32``: BiSeNet's ResNet-18 stem); ``out`` may be a 64-channel slice.  The activation
+    is split hi + lo while it is staged and a k-step is the full three-term product; K order (kh, kw, c), i.e. the
+    accuracy class of ``conv`` + ``maxpool3x3s2`` with a different summation order."""
+    assert x4.fmt == 0 and x4.c0 == 0 and x4.c == 4 and x4.ld == 4, "the fused fp32 stem reads a dense NHWC4 tensor"
+    n, h, w = x4.n, x4.h, x4.w
+    hs, ws = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    hp, wp = (hs - 1) // 2 + 1, (ws - 1) // 2 + 1
+    if out is None:
+        out = Act.empty(n, hp, wp, 64, x4.buf.device, out_fmt)
+    assert (out.n, out.h, out.w, out.c) == (n, hp, wp, 64), "stem: bad output view"
+    timing = ConvStats.timing
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    N.check(N.lib().fcp_stem7x7s2_relu_pool_f32(x4.ptr(), n, h, w, N.ptr(ps.wfrag), N.ptr(ps.bias), N.ptr(ps.wscale),
+                                                out.ptr(), out.ld, out.fmt, N.stream_ptr()), "fcp_stem7x7s2_relu_pool_f32")
+    flops = ps.flops_per_pixel * n * hs * ws
+    if timing is not None:
+        e1.record()
+        timing.append((e0, e1, flops, f"stem(f32) 7x7 s2 + pool @{hp}x{wp}", n * h * w * 16 + 4 * n * hp * wp * 64))
+    if ConvStats.enabled:
+        ConvStats.flops += flops
+        ConvStats.launches += 1
+    if RangeMonitor.active is not None:
+        _monitor(f"stem(f32) 7x7 s2 + pool @{hp}x{wp}", out)
+    return out
+
+
 def f32nchw_to_nhwc4(images: torch.Tensor, sub=(0.0, 0.0, 0.0), div: float = 1.0) -> Act:
     """(n,3,h,w) fp32 device tensor -> fp32 NHWC4 activation ((x - sub) / div)."""
     assert images.dtype == torch.float32 and images.dim() == 4 and images.shape[1] == 3

@@ -233,6 +233,13 @@ int fcp_stem7x7s2_relu_pool_conv1_u8(const uint8_t* images, int n, int h, int w,
                                      const void* wfrag, const float* bias, const float* wscale, float* out,
                                      int out_ld, int out_fmt, const void* w1, const float* ws1, const float* b1,
                                      float* t1, int t1_ld, fcp_stream_t stream);
+/* The same stem on an fp32 NHWC4 input (n, h, w, 4; channel 3 ignored) that is already normalised: BiSeNet's ResNet-18 stem
+ * (conv1 7x7 / 2 + bn1 + relu + maxpool 3x3 / 2; bise.py:387-393 feeds it, _layers.py:241-247 is the stem).  The input has a lo part,
+ * so the patch is staged as hi + lo binary16 planes and a k-step is the full three-term product (al*wh + ah*wl + ah*wh).  wfrag /
+ * bias / wscale: engine.py::pack_stem_fused (no channel permutation).  The 256 x 256 x 64 stem map of a 512 x 512 face (537 MB for 32
+ * faces) never reaches HBM. */
+int fcp_stem7x7s2_relu_pool_f32(const float* x4, int n, int h, int w, const void* wfrag, const float* bias,
+                                const float* wscale, float* out, int out_ld, int out_fmt, fcp_stream_t stream);
 /* Format converters between fp32 NHWC and split32 (npix pixels of c channels, c % 32 == 0). */
 int fcp_f32_to_split32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream);
 int fcp_split32_to_f32(const float* in, float* out, int64_t npix, int c, fcp_stream_t stream);

@@ -636,3 +636,44 @@ def test_autotune_does_not_corrupt_in_place_ops(device, precision):
             E.Autotune.enabled, E.Autotune.cache = prev, saved
         outs.append(tgt.buf.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 77, 91), (1, 64, 64), (3, 50, 130), (1, 9, 200), (2, 512, 512)])
+def test_fused_stem_pool_f32_input(n, h, w, device, precision):
+    """Round 5: the fused stem on a normalised fp32 NHWC4 input (BiSeNet's ResNet-18 stem): conv 7x7 / 2 (BatchNorm folded) ->
+    ReLU -> max-pool 3x3 / 2 in one launch, the activation split hi + lo while it is staged.  Against torch fp32 of the three
+    ops, against the unfused engine path (conv + max-pool: same accuracy class, different summation order), split32 and fp32
+    outputs equal after decoding, odd sizes and border patches, and a channel slice of a wider buffer."""
+    if precision != "f16x3":
+        pytest.skip("the fused stem exists on the fp16x3 path")
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(n + h * 3 + w)
+    x = torch.randn(n, 3, h, w, generator=g) * 1.3 + 0.2                 # (x / 255 - mean) / std has this range
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 12
+    bn = {"weight": torch.rand(64, generator=g) + 0.5, "bias": torch.randn(64, generator=g) * 0.1,
+          "running_mean": torch.randn(64, generator=g) * 0.1, "running_var": torch.rand(64, generator=g) + 0.5}
+    ref = F.max_pool2d(F.relu(F.batch_norm(F.conv2d(x, wt, None, 2, 3), bn["running_mean"], bn["running_var"], bn["weight"],
+                                           bn["bias"], False, 0.0, 1e-5)), 3, 2, 1)
+    x4 = torch.zeros(n, h, w, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    x4[..., 3] = 7.0                                                      # channel 3 must be ignored
+    xa = E.Act(x4.to(device))
+    ps = E.pack_stem_fused(wt, bn, device)
+    out1 = E.stem_relu_pool_f32(ps, xa, out_fmt=1)
+    out0 = E.stem_relu_pool_f32(ps, xa, out_fmt=0)
+    assert out1.fmt == 1 and tuple(out1.nchw().shape) == tuple(ref.shape)
+    # the split32 image is the fp32 result cut to hi + lo (22 significant bits)
+    assert (out1.nchw() - out0.nchw()).abs().max().item() <= 2.0 ** -20 * float(ref.abs().max())
+    err = (out0.nchw().cpu() - ref).abs().max().item()
+    assert err <= _tol(ref), err
+    x4z = x4.clone(); x4z[..., 3] = 0.0                                   # the generic cin4 kernel multiplies channel 3 by zero weights
+    pc = E.pack_conv(wt, None, bn, 2, 3, device)
+    unfused = E.maxpool3x3s2(E.conv(pc, E.Act(x4z.to(device)), act_slope=0.0, out_fmt=1))
+    assert (unfused.nchw().cpu() - out1.nchw().cpu()).abs().max().item() <= _tol(ref)
+    wide = E.Act.empty(n, ref.shape[2], ref.shape[3], 128, device, 1)
+    wide.buf.zero_()
+    E.stem_relu_pool_f32(ps, xa, wide.slice(64, 64))
+    got = wide.nchw()
+    assert torch.equal(got[:, 64:], out1.nchw()) and got[:, :64].abs().max().item() == 0
+    again = E.stem_relu_pool_f32(ps, xa, out_fmt=1)
+    assert torch.equal(again.buf, out1.buf)
