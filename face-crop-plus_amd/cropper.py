@@ -465,17 +465,25 @@ class Cropper:
             pass
         return False
 
+    @staticmethod
+    def default_io_processes(cores: int, local_world: int = 1):
+        """(decode, encode) worker processes of one ``Cropper`` on a host with ``cores`` usable cores shared by
+        ``local_world`` ranks (one process per GPU: the ranks of a node share the host).  Measured on a 2 x 64-core EPYC
+        9575F box (2048 JPEGs of 640^2, one decode request per decoder and batch; 2 / 3 GPU workers): (8, 3) 2320 / 2650,
+        (12, 3) 2360 / 2750, (12, 4) 2300 / 2540, (16, 4) 2270 / 2600, (24, 4) 2110 / 2650 images/s — flat beyond a dozen
+        decoders (one decodes ~600 images/s).  8 ranks on that box: 16 cores each -> (5, 2), i.e. 40 + 16 I/O processes,
+        8 x (1 + num_processes) Python threads that enqueue, and 3000 decodes/s per rank against ~3500 faces/s of device
+        rate."""
+        cores = max(1, cores // max(1, local_world))
+        return (max(2, min(12, cores // 3)), max(1, min(3, cores // 8)))
+
     def _io_processes(self):
         """The decode / encode worker processes of this Cropper (started on first use, reused by later runs), or None
         when they are switched off or cannot be had on this platform."""
         want = self.io_processes
         if want is None:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
-            cores //= max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))      # one process per GPU: share the host
-            # measured on a 2 x 64-core EPYC 9575F box (2048 JPEGs of 640^2, one decode request per decoder and batch;
-            # 2 / 3 GPU workers): (8, 3) 2320 / 2650, (12, 3) 2360 / 2750, (12, 4) 2300 / 2540, (16, 4) 2270 / 2600,
-            # (24, 4) 2110 / 2650 images/s — flat beyond a dozen decoders (one decodes ~600 images/s)
-            want = (max(2, min(12, cores // 3)), max(1, min(3, cores // 8)))
+            want = self.default_io_processes(cores, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
         if min(want) <= 0:
             return None
         have = self._io_procs

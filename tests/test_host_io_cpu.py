@@ -202,3 +202,17 @@ def test_selfcheck_mode_policy(monkeypatch):
     assert not E.selfcheck_mode(None)
     monkeypatch.setenv("FCP_SELFCHECK", "1")
     assert E.selfcheck_mode("generated") and E.selfcheck_mode({"a": 1})
+
+
+def test_io_workers_are_divided_between_the_ranks_of_a_node():
+    """Pre-flight for the 8-GPU node: one process per GPU, the ranks of a node share the host's cores — every rank sizes its
+    decode / encode worker pool for cores / LOCAL_WORLD_SIZE (DESIGN.md section 6 carries the table this pins)."""
+    from face_crop_plus_amd.cropper import Cropper
+    f = Cropper.default_io_processes
+    assert f(128, 1) == (12, 3)          # the measured optimum on the 2 x 64-core box
+    assert f(128, 8) == (5, 2)           # 8 ranks: 16 cores each -> 40 decoders + 16 encoders on the node
+    assert f(256, 8) == (10, 3)
+    assert f(16, 8) == (2, 1)            # never below a working pool
+    assert f(4, 1) == (2, 1)
+    total = lambda cores, r: r * sum(f(cores, r))
+    assert total(128, 8) <= 128 and total(256, 8) <= 256      # the node is not oversubscribed by I/O processes
