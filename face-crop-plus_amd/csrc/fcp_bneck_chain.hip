@@ -109,10 +109,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 // one-KiB vector-memory instructions a tile issues — and the chain kernels are bound by exactly that path
 // (profiles/r04_probes.md section 1: same cycles with and without their MFMAs).  The halo form issues 46.  Same K order (channel
 // slice outer, taps inner), same terms: bit-identical.
+#ifdef FCP_CHAIN_DIRECT_L3     // A/B builds (tools/ab_define_table.sh): the one-source layer-3 pair with its fragments straight from global memory too
+constexpr bool direct_form(int cw, int cw2, bool has_c2, int bmt) { return cw2 > 0 || (!has_c2 && bmt == 128 && cw == 256); }
+#else
+constexpr bool direct_form(int cw, int cw2, bool has_c2, int bmt) { return cw2 > 0; }
+#endif
 template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false, int CW2 = 0>
-__global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, CW2 > 0) * BMT / 128) bneck_chain_c64(const ChainK p) {
-  constexpr bool DIRECT = CW2 > 0;                  // two-source pair: CW - CW2 channels from t1, CW2 from t1b; fragments loaded straight from global memory
-  static_assert(!DIRECT || (!HAS_C2 && BMT == 128 && CW2 % 32 == 0 && CW2 < CW), "two-source forms are pair forms on 128-pixel tiles");
+__global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, direct_form(CW, CW2, HAS_C2, BMT)) * BMT / 128) bneck_chain_c64(const ChainK p) {
+  constexpr bool DIRECT = direct_form(CW, CW2, HAS_C2, BMT);   // fragments loaded straight from global memory: the two-source pair (CW - CW2 channels from t1, CW2 from t1b)
+  static_assert(!DIRECT || (!HAS_C2 && BMT == 128 && CW2 % 32 == 0 && CW2 < CW), "direct forms are pair forms on 128-pixel tiles");
   static_assert(!HAS_C2 || CW == C, "phase 1 is written for 64-channel bottlenecks");
   static_assert(!PATCH || HAS_C2, "the patch form is a conv2 form");
   constexpr int PH = BMT / 16;                      // PATCH: rows of the (PH x 16)-pixel patch: 8 (4 waves) or 16 (8 waves)
@@ -943,7 +948,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, CW2 >
 
 template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false, int CW2 = 0>
 int launch(const ChainK& k, hipStream_t s) {
-  constexpr int LDS = lds_bytes(BMT, CW, CN, HAS_C2, CW2 > 0);
+  constexpr int LDS = lds_bytes(BMT, CW, CN, HAS_C2, direct_form(CW, CW2, HAS_C2, BMT));
   FCP_LDS_OPT_IN((&bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH, CW2>), LDS);
   const int tiles = PATCH ? k.n * fcp_cdiv(k.h, BMT / 16) * ((k.w + 15) >> 4) : fcp_cdiv(k.M, BMT);
   hipLaunchKernelGGL((bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH, CW2>), dim3(tiles), dim3(2 * BMT), LDS, s, k);

@@ -33,4 +33,18 @@ for case in range(cases):
             and torch.equal(outl.buf, o3.buf) and torch.equal(t1nl.buf, o1.buf)):
         bad += 1
         print(f"MISMATCH case {case}: form {(c, nout, cn, has_c2, residual)} n={n} h={h} w={w}", flush=True)
+# the two-source pair (layer2.0: conv3 + stride-s downsample over [t (128 ch) | x(::s, ::s) (256 ch)], next conv1 512 -> 128)
+for case in range(max(1, cases // 6)):
+    n, h, w, st = ri(1, 3), ri(1, 40), ri(1, 40), ri(1, 2)
+    hx, wx = (h - 1) * st + ri(1, st), (w - 1) * st + ri(1, st)
+    pc3, pc1 = mk(512, 384, 1), mk(128, 512, 1)
+    t = E.f32_to_split32(E.Act(torch.randn(n, h, w, 128, generator=g).relu().to(dev)))
+    xb = E.f32_to_split32(E.Act(torch.randn(n, hx, wx, 256, generator=g).relu().to(dev)))
+    o3 = E.conv(pc3, t, act_slope=0.0, out_fmt=1, x2=xb, x2_stride=st)
+    o1 = E.conv(pc1, o3, act_slope=0.0, out_fmt=1)
+    out, t1n = E.bottleneck_chain(None, pc3, pc1, t, None, t1b=xb, t1b_stride=st)
+    torch.cuda.synchronize()
+    if not (torch.equal(out.buf, o3.buf) and torch.equal(t1n.buf, o1.buf)):
+        bad += 1
+        print(f"MISMATCH two-source case {case}: n={n} h={h} w={w} stride={st} x {hx}x{wx}", flush=True)
 print(f"{cases} cases, {bad} bad")
