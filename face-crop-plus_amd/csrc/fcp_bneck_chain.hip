@@ -109,11 +109,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // one-KiB vector-memory instructions a tile issues — and the chain kernels are bound by exactly that path
 // (profiles/r04_probes.md section 1: same cycles with and without their MFMAs).  The halo form issues 46.  Same K order (channel
 // slice outer, taps inner), same terms: bit-identical.
-#ifdef FCP_CHAIN_DIRECT_L3     // A/B builds (tools/ab_define_table.sh): the one-source layer-3 pair with its fragments straight from global memory too
-constexpr bool direct_form(int cw, int cw2, bool has_c2, int bmt) { return cw2 > 0 || (!has_c2 && bmt == 128 && cw == 256); }
-#else
 constexpr bool direct_form(int cw, int cw2, bool has_c2, int bmt) { return cw2 > 0; }
-#endif
 template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false, int CW2 = 0>
 __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, direct_form(CW, CW2, HAS_C2, BMT)) * BMT / 128) bneck_chain_c64(const ChainK p) {
   constexpr bool DIRECT = direct_form(CW, CW2, HAS_C2, BMT);   // fragments loaded straight from global memory: the two-source pair (CW - CW2 channels from t1, CW2 from t1b)
