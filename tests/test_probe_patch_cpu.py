@@ -16,6 +16,13 @@ def test_experiment_patch_applies_to_current_sources():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+@pytest.mark.skipif(shutil.which("patch") is None, reason="patch(1) not installed")
+def test_epilogue_ab_patch_applies_to_current_sources():
+    with open(os.path.join(ROOT, "tools", "probes", "epilogue_serial_r05.patch")) as f:
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-s"], stdin=f, cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_product_kernels_carry_no_experiment_switches():
     import re
     bad = []
