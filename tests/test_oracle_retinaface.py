@@ -82,3 +82,48 @@ def test_full_forward_and_predict_match_reference():
         lm, idx = R.predict(x, sd, strat, thr)
         assert idx == d[f"pred_{strat}_{thr}_indices"].tolist()
         np.testing.assert_allclose(lm, d[f"pred_{strat}_{thr}_landmarks"], rtol=0, atol=1e-3)
+
+
+def test_resnet50_body_matches_transformers_resnet():
+    """Third-party pin of the body topology (row a3): tests/golden/hf_resnet50.npz holds the stage 2-4 outputs of Hugging Face
+    transformers' ResNetModel (an independent ResNet-50 v1.5, `downsample_in_bottleneck=False`) on the build's generated `body.*`
+    weights (make_golden_hf_resnet.py).  The oracle's body must reproduce them — and the classic wrong topologies must NOT:
+    the stride on conv1 instead of conv2 (ResNet v1), or a stem pool without padding."""
+    import torch.nn.functional as F
+    from face_crop_plus_amd import weights
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hf_resnet50.npz"))
+    print("fixture from transformers", z["transformers_version"], "torch", z["torch_version"], str(z["config"]))
+    sd = weights.generate_state_dict("retinaface")
+    x = torch.from_numpy(z["x"])
+    with torch.no_grad():
+        feats = R.body(x, sd)
+    for k, f in enumerate(feats, 1):
+        ref = z[f"feat{k}"]
+        assert tuple(f.shape) == ref.shape
+        err = float(np.abs(f.numpy() - ref).max()) / float(np.abs(ref).max())
+        assert err < 1e-5, (k, err)
+
+    def body_variant(stride_on_conv1, pool_pad):
+        t = F.relu(R._bn(R._conv(x, sd, "body.conv1", 2, 3), sd, "body.bn1"))
+        t = F.max_pool2d(t, 3, 2, pool_pad)
+        out = []
+        for li, blocks in enumerate((3, 4, 6, 3), 1):
+            for b in range(blocks):
+                p, s = f"body.layer{li}.{b}", 2 if (b == 0 and li > 1) else 1
+                s1, s2 = (s, 1) if stride_on_conv1 else (1, s)
+                o = F.relu(R._bn(R._conv(t, sd, p + ".conv1", s1), sd, p + ".bn1"))
+                o = F.relu(R._bn(R._conv(o, sd, p + ".conv2", s2, 1), sd, p + ".bn2"))
+                o = R._bn(R._conv(o, sd, p + ".conv3"), sd, p + ".bn3")
+                if (p + ".downsample.0.weight") in sd:
+                    t = R._bn(R._conv(t, sd, p + ".downsample.0", s), sd, p + ".downsample.1")
+                t = F.relu(o + t)
+            if li >= 2:
+                out.append(t)
+        return out
+
+    with torch.no_grad():
+        same = body_variant(False, 1)
+        assert all(torch.equal(a, b) for a, b in zip(same, feats))                      # the helper restates R.body
+        v1 = body_variant(True, 1)                                                       # ResNet v1: stride on the first 1x1
+        assert all(a.shape == b.shape for a, b in zip(v1, feats))                        # every shape survives ...
+        assert float(np.abs(v1[0].numpy() - z["feat1"]).max()) / float(np.abs(z["feat1"]).max()) > 1e-2   # ... the pin does not

@@ -147,3 +147,31 @@ def test_two_stream_split_is_bit_identical(n, h, w, sd, device):
     res3 = det.detect(img)
     torch.cuda.synchronize()
     assert torch.equal(res1["landmarks"], res3["landmarks"]) and torch.equal(res1["face_offset"], res3["face_offset"])
+
+
+def test_body_matches_transformers_resnet(sd, device):
+    """Third-party pin of the ResNet-50 body on the GPU (row a3): the three feature maps the HIP kernels hand to the FPN against
+    Hugging Face transformers' ResNetModel outputs on the same generated weights (tests/golden/hf_resnet50.npz,
+    make_golden_hf_resnet.py) — an independent implementation of the topology the reference takes from torchvision
+    (retinaface.py:93-99): [3, 4, 6, 3] bottlenecks, stride on the 3x3, 1x1 / stride shortcut, stem 7x7 / 2 + MaxPool(3, 2, 1)."""
+    import os
+    from face_crop_plus_amd import engine as E
+    from face_crop_plus_amd.retinaface import RetinaFace
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hf_resnet50.npz"))
+    for precision, tol in (("f16x3", 2e-5), ("f32", 2e-5)):
+        det = RetinaFace("all", 0.6).load(device, sd, precision)
+        x = torch.from_numpy(z["x"]).to(device)
+        # the detector's stem expects RGB - mean in NHWC4 and folds the BGR swap into its filter's channel order; the fixture's
+        # model saw `x` as is: feed the channels reversed so that the filter's permutation restores the fixture's order
+        x4 = E.f32nchw_to_nhwc4(x.flip(1).contiguous())
+        det._debug_feats = feats = []
+        det.forward_heads(x4)
+        torch.cuda.synchronize()
+        assert len(feats) == 3
+        for k, f in zip((1, 2, 3), feats):
+            ref = z[f"feat{k}"]
+            got = f.nchw().cpu().numpy()
+            assert got.shape == ref.shape
+            err = float(np.abs(got - ref).max()) / float(np.abs(ref).max())
+            print(f"{precision} stage {k + 1}: relative error vs transformers {z['transformers_version']} ResNetModel {err:.2e}")
+            assert err < tol, (precision, k, err)
