@@ -154,3 +154,28 @@ def test_area_integral_ratios_match_scikit_image_block_means():
         assert np.abs(got - mean).max() <= 0.5 + 1 / 64, (f, np.abs(got - mean).max())      # a rounding of the same mean
         off_tie = np.abs(mean - np.floor(mean) - 0.5) > 1 / 32
         assert np.array_equal(got[off_tie], np.rint(mean)[off_tie])                              # identical away from exact ties
+
+
+@pytest.mark.parametrize("shape,dst", [((40, 64), (160, 100)), ((33, 21), (64, 100)), ((64, 48), (160, 213)), ((7, 9), (30, 23))])
+def test_cubic_upscale_matches_torch_bicubic(shape, dst):
+    """Third-party check of row f1's INTER_CUBIC leg (the reference only up-scales with it, utils.py:316-320): PyTorch's
+    `F.interpolate(mode="bicubic", align_corners=False)` is an independently written implementation of the same filter —
+    Keys cubic with A = -0.75, half-pixel centres, source indices clamped at the border — evaluated in float32.  The oracle's
+    OpenCV restatement (int16 coefficients with 11 fractional bits, two fixed-point passes, saturating round) must agree with
+    it within the rounding of those coefficients; a different A (Pillow's -0.5), a different centre convention or a different
+    border rule would miss by tens of grey levels.  OpenCV's own rounding stays unpinned (no cv2 in the image)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    img = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+    dw, dh = dst
+    got = B.resize_cubic_u8(img, dw, dh).astype(np.float64)
+    t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+    ref = F.interpolate(t, size=(dh, dw), mode="bicubic", align_corners=False)[0].permute(1, 2, 0).clamp(0, 255).numpy().astype(np.float64)
+    d = np.abs(got - ref)
+    print(f"{shape} -> {(dh, dw)}: max |oracle - torch bicubic| = {d.max():.3f} grey levels, mean {d.mean():.3f}")
+    assert d.max() <= 0.5 + 0.6 and d.mean() < 0.3
+    # the same comparison with the filter Pillow / many others use (A = -0.5) shows what the check excludes
+    from oracle import batch_ref
+    if hasattr(batch_ref, "_cubic_coeffs"):
+        assert abs(float(batch_ref._cubic_coeffs(np.array([0.5], np.float32))[0][0]) - (-0.09375)) < 1e-7     # A = -0.75 -> -3/32
