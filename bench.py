@@ -599,10 +599,12 @@ def main():
                     where["north_star_geometry_steps"] = ns["steps"]
                     where["north_star_geometry_frac"] = ns["roofline"]["frac"]
                     where["north_star_geometry_frac_timed"] = ns["roofline"].get("frac_timed")
-        # the long side records first, the contract fields last: a consumer that keeps only the tail of the line sees the
-        # headline, `config`, `roofline` and `cpu_baseline`
-        first = [k for k in ("extra", "hbm_kernels", "parity_check", "weight_broadcast") if k in line]
-        line = {**{k: line[k] for k in first}, **{k: v for k, v in line.items() if k not in first}}
+        # Key order: the contract's scalar fields first (the line starts with {"metric": ...), the long side records in the
+        # middle, `config` / `roofline` / `cpu_baseline` last — a consumer that keeps only the tail of the line still sees the
+        # workload, the roofline and the north-star record
+        last = [k for k in ("config", "roofline", "cpu_baseline") if k in line]
+        line = {**{k: v for k, v in line.items() if k not in last}, **{k: line[k] for k in last}}
+        assert next(iter(line)) == "metric"
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -11,11 +11,11 @@ O=$R/gpurun_out/prof_$P
 mkdir -p $O
 CMD="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extra --streams 1 --precision $P"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- $CMD > $O/bench_trace.log 2>&1
-grep '^{.*"metric"' $O/bench_trace.log | tail -1 > $O/bench_line_under_trace.json
+grep '^{"metric"' $O/bench_trace.log | tail -1 > $O/bench_line_under_trace.json
 CMD1="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra --streams 1 --precision $P"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o b -- $CMD1 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o b -- $CMD1 > $O/write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sq -o b -- $CMD1 > $O/sq.log 2>&1
-python $R/bench.py --precision $P 2>/dev/null | grep '^{.*"metric"' | tail -1 > $O/bench_line.json
+python $R/bench.py --precision $P 2>/dev/null | grep '^{"metric"' | tail -1 > $O/bench_line.json
 find $O -name "*.csv" | head -20
 cut -c1-260 $O/bench_line.json

@@ -13,7 +13,7 @@ mkdir -p $O
 BASE="python $R/bench.py --no-cpu-baseline --no-extra $*"
 if [ "$WHAT" = trace ] || [ "$WHAT" = all ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- $BASE --steps 3 --warmup 2 --streams 1 > $O/bench_trace.log 2>&1
-  grep '^{.*"metric"' $O/bench_trace.log | tail -1 > $O/bench_line_under_trace.json
+  grep '^{"metric"' $O/bench_trace.log | tail -1 > $O/bench_line_under_trace.json
   rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -o b -- $BASE --steps 3 --warmup 2 --streams 2 > $O/bench_trace2.log 2>&1
 fi
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
@@ -21,7 +21,7 @@ if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o b -- $CMD1 > $O/fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o b -- $CMD1 > $O/write.log 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sq -o b -- $CMD1 > $O/sq.log 2>&1
-  grep '^{.*"metric"' $O/sq.log | tail -1 > $O/bench_line_under_pmc.json
+  grep '^{"metric"' $O/sq.log | tail -1 > $O/bench_line_under_pmc.json
 fi
 # keep what the reducers need, drop the bulky rest (gpurun_out is capped at 64 MiB)
 find $O -name "*agent_info.csv" -delete

@@ -11,5 +11,5 @@ while kill -0 $PID 2>/dev/null; do
   sleep 0.3
 done
 wait $PID
-grep '^{.*"metric"' ${OUT%.log}_cmd.log | cut -c1-160
+grep '^{"metric"' ${OUT%.log}_cmd.log | cut -c1-160
 echo "samples: $(wc -l < $OUT)"; sort $OUT | uniq -c | sort -rn | head -8
