@@ -360,11 +360,34 @@ class Autotune:
             cls.cache[key] = best
             cls._disk_dirty = True
         if os.environ.get("FCP_TUNE_CACHE") != "0":
-            try:
-                cls.save()
-            except Exception:                                # read-only home, full disk, a damaged file: tuning still works in-process
-                pass
+            cls._save_soon()
         return best
+
+    _last_save = 0.0
+    _atexit = False
+
+    @classmethod
+    def _save_soon(cls):
+        """Persist new picks at most once every two seconds (a tuning pass meets dozens of new shapes in a row and every save is
+        a read-modify-write of the user's file), and once more at interpreter exit if something is still unsaved."""
+        import time
+        if not cls._atexit:
+            import atexit
+            cls._atexit = True
+            atexit.register(cls._save_quietly)
+        if time.monotonic() - cls._last_save >= 2.0:
+            cls._save_quietly()
+
+    @classmethod
+    def _save_quietly(cls):
+        import time
+        if not cls._disk_dirty or os.environ.get("FCP_TUNE_CACHE") == "0":
+            return
+        try:
+            cls.save()
+        except Exception:                                    # read-only home, full disk, a damaged file: tuning still works in-process
+            pass
+        cls._last_save = time.monotonic()
 
 
 class ConvStats:

@@ -46,3 +46,24 @@ def test_damaged_or_disabled_table_is_harmless(tuner, tmp_path, monkeypatch):
     monkeypatch.setattr(tuner, "_disk_loaded", False)
     tuner.ensure_loaded()
     assert tuner.cache == {} and tuner.save() is None
+
+
+def test_new_picks_are_saved_with_a_debounce_and_at_exit(tuner, tmp_path, monkeypatch):
+    """A tuning pass meets dozens of new shapes in a row: the user's table is rewritten at most once every two seconds, and what
+    is still unsaved goes out through the atexit hook (`_save_quietly`); a failing save never escapes."""
+    import time
+    path = tmp_path / "tune.json"
+    monkeypatch.setattr(tuner, "_last_save", 0.0)
+    tuner.cache[(1,)] = (128, 64)
+    monkeypatch.setattr(tuner, "_disk_dirty", True)
+    tuner._save_soon()                                     # first pick: saved at once
+    assert json.loads(path.read_text())["gfx950|256|abi0"] == {"(1,)": [128, 64]}
+    tuner.cache[(2,)] = (256, 256)
+    monkeypatch.setattr(tuner, "_disk_dirty", True)
+    tuner._save_soon()                                     # within two seconds: not yet
+    assert "(2,)" not in json.loads(path.read_text())["gfx950|256|abi0"]
+    tuner._save_quietly()                                  # what atexit runs
+    assert "(2,)" in json.loads(path.read_text())["gfx950|256|abi0"] and tuner._disk_dirty is False
+    monkeypatch.setattr(tuner, "_disk_dirty", True)
+    monkeypatch.setattr(tuner, "save", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("dictionary changed size during iteration")))
+    tuner._save_quietly()                                  # swallowed: tuning still works in-process
