@@ -90,7 +90,10 @@ constexpr int lds_bytes(int bmt, int cw, int cn, bool has_c2, bool direct = fals
   return !alias_t2(bmt, cw, cn, has_c2) ? r0 + t2 : (r0 > w1b_off(bmt) + t2 ? r0 : w1b_off(bmt) + t2);
 }
 constexpr int wgs_per_cu(int bmt, int cw, int cn, bool has_c2, bool direct = false) {
-  return bmt == 128 && !direct && lds_bytes(bmt, cw, cn, has_c2) <= 80 * 1024 ? 2 : 1;   // (the DIRECT forms hold 48 fragments: one wave per SIMD)
+  // the two-source DIRECT pair holds 48 fragments + conv1's accumulators: one wave per SIMD; the EXPAND form (cn = 0: conv3 only,
+  // no conv1' — no accumulators, no conv1' buffers: 80 KiB, < 256 registers) runs two workgroups per CU
+  if (direct) return bmt == 128 && cn == 0 && lds_bytes(bmt, cw, cn, has_c2, true) <= 80 * 1024 ? 2 : 1;
+  return bmt == 128 && lds_bytes(bmt, cw, cn, has_c2) <= 80 * 1024 ? 2 : 1;
 }
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
@@ -109,11 +112,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 // one-KiB vector-memory instructions a tile issues — and the chain kernels are bound by exactly that path
 // (profiles/r04_probes.md section 1: same cycles with and without their MFMAs).  The halo form issues 46.  Same K order (channel
 // slice outer, taps inner), same terms: bit-identical.
-constexpr bool direct_form(int cw, int cw2, bool has_c2, int bmt) { return cw2 > 0; }
+// Direct forms (operand fragments straight from global memory, no LDS tile): the two-source pair (cw2 > 0) and the EXPAND form
+// (cn = 0, round 5): conv3 + identity of a block WITHOUT the next block's conv1 — out = relu(conv3(t1) + res) and nothing else.
+// Where the pair needs one wave per SIMD (layer 3: 128 accumulator + 128 fragment registers), the expand form needs 128 + 16 and
+// 80 KiB, i.e. two workgroups per CU like the forms that sit nearest their floors, and conv1' runs on the 256-row kernel.
+constexpr bool direct_form(int cn, int cw2) { return cw2 > 0 || cn == 0; }
 template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false, int CW2 = 0>
-__global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, direct_form(CW, CW2, HAS_C2, BMT)) * BMT / 128) bneck_chain_c64(const ChainK p) {
-  constexpr bool DIRECT = direct_form(CW, CW2, HAS_C2, BMT);   // fragments loaded straight from global memory: the two-source pair (CW - CW2 channels from t1, CW2 from t1b)
+__global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, direct_form(CN, CW2)) * BMT / 128) bneck_chain_c64(const ChainK p) {
+  constexpr bool DIRECT = direct_form(CN, CW2);   // fragments loaded straight from global memory: the two-source pair (CW - CW2 channels from t1, CW2 from t1b)
   static_assert(!DIRECT || (!HAS_C2 && BMT == 128 && CW2 % 32 == 0 && CW2 < CW), "direct forms are pair forms on 128-pixel tiles");
+  constexpr bool HAS_P3 = CN > 0;                   // conv1' of the next block (phase 3); false: the expand form
   static_assert(!HAS_C2 || CW == C, "phase 1 is written for 64-channel bottlenecks");
   static_assert(!PATCH || HAS_C2, "the patch form is a conv2 form");
   constexpr int PH = BMT / 16;                      // PATCH: rows of the (PH x 16)-pixel patch: 8 (4 waves) or 16 (8 waves)
@@ -124,6 +132,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, direc
   constexpr int STAGE = stage_bytes(BMT);
   constexpr int W1B_OFF = w1b_off(BMT);
   constexpr int TN3 = CN / 32;
+  constexpr int TN3A = TN3 > 0 ? TN3 : 1;           // array extents (the expand form has no conv1' tiles)
   constexpr int CS = CW / 32;                       // K slices of conv3
   constexpr int NCH = NOUT / 32;                    // groups of 32 conv3 filters
   constexpr int W3CH = CW * 128;                    // bytes of one conv3 filter group in LDS
@@ -483,7 +492,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, direc
   // conv3 filter group j: 32 rows x CS K slices = 4 CS pieces of 8 rows.  Wave w moves pieces w PW3 .. w PW3 + PW3 - 1.
   constexpr int PW3 = 4 * CS / NW;                  // per wave: CS (4 waves) | CS / 2 (8 waves)
   constexpr int PW1 = CN / (8 * NW);                // conv1' slice: CN rows, 8 per wave instruction
-  static_assert(PW3 >= 1 && PW1 >= 1, "filter pieces per wave");
+  static_assert(PW3 >= 1 && (PW1 >= 1 || !HAS_P3), "filter pieces per wave");
   auto dma_w3 = [&](int j, int buf) {
 #pragma unroll
     for (int i = 0; i < PW3; ++i) {
@@ -522,7 +531,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, direc
     }
   };
 
-  f32x16 acc3[TN3];
+  f32x16 acc3[TN3A];
 #pragma unroll
   for (int t = 0; t < TN3; ++t)
 #pragma unroll
@@ -685,7 +694,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, direc
     read_b2(0, 0);
     // conv1' fragments of this chunk (W1DB: slice j landed with filter group j): requested behind the phase-2 operands,
     // they arrive under the phase-2 MFMAs and phase 3 starts with only its two T3 fragments per k-half to wait for
-    f16x8 dh[2][TN3], dl[2][TN3];                                // [k-half][column tile]
+    f16x8 dh[2][TN3A], dl[2][TN3A];                              // [k-half][column tile]
     if constexpr (W1PRE) {
       const char* w1b = lds + W1B_OFF + (j & 1) * (CN * ROWB);
 #pragma unroll
@@ -795,8 +804,10 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, direc
         v[e] = x * 1.f;
       }
       split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, ohi[it], olo[it]);
-      *reinterpret_cast<u32x4_t*>(crow + ((eq ^ sw) << 4)) = ohi[it];
-      *reinterpret_cast<u32x4_t*>(crow + (((4 + eq) ^ sw) << 4)) = olo[it];
+      if constexpr (HAS_P3) {                                      // ... and T3, conv1's operand (the expand form has no phase 3)
+        *reinterpret_cast<u32x4_t*>(crow + ((eq ^ sw) << 4)) = ohi[it];
+        *reinterpret_cast<u32x4_t*>(crow + (((4 + eq) ^ sw) << 4)) = olo[it];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
@@ -822,7 +833,9 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, direc
         __builtin_amdgcn_raw_buffer_store_b128(olo[it], rs_out, o == 0xFFFFFFFFu ? o : o + 64u, 0, FCP_CHAIN_STORE_AUX);
       }
     };
-    if constexpr (ROT) {
+    if constexpr (!HAS_P3) {
+      store_out();                                                 // expand form: the chunk ends with its stores
+    } else if constexpr (ROT) {
       // rotated loop: T3 of this chunk goes to registers now (the tile is overwritten by the next chunk's staging); its
       // phase 3 rides in the next chunk's phase 2.  The chunk's `out` stores go out behind the fragment reads.
 #pragma unroll
@@ -944,7 +957,7 @@ __global__ void __launch_bounds__(2 * BMT, wgs_per_cu(BMT, CW, CN, HAS_C2, direc
 
 template <int CN, int CW, int NOUT, bool HAS_C2, bool HAS_RES, int BMT, bool PATCH = false, int CW2 = 0>
 int launch(const ChainK& k, hipStream_t s) {
-  constexpr int LDS = lds_bytes(BMT, CW, CN, HAS_C2, direct_form(CW, CW2, HAS_C2, BMT));
+  constexpr int LDS = lds_bytes(BMT, CW, CN, HAS_C2, direct_form(CN, CW2));
   FCP_LDS_OPT_IN((&bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH, CW2>), LDS);
   const int tiles = PATCH ? k.n * fcp_cdiv(k.h, BMT / 16) * ((k.w + 15) >> 4) : fcp_cdiv(k.M, BMT);
   hipLaunchKernelGGL((bneck_chain_c64<CN, CW, NOUT, HAS_C2, HAS_RES, BMT, PATCH, CW2>), dim3(tiles), dim3(2 * BMT), LDS, s, k);
@@ -956,7 +969,8 @@ int launch(const ChainK& k, hipStream_t s) {
 
 extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t stream) {
   FCP_REQUIRE(d != nullptr, "chain: null descriptor");
-  FCP_REQUIRE(d->t1 && d->w3 && d->ws3 && d->b3 && d->out && d->w1n && d->ws1n && d->b1n && d->t1n,
+  const bool has_p3 = d->cn != 0 || d->w1n != nullptr;          // cn = 0 and no conv1' filter: the expand form (conv3 + identity only)
+  FCP_REQUIRE(d->t1 && d->w3 && d->ws3 && d->b3 && d->out && (!has_p3 || (d->w1n && d->ws1n && d->b1n && d->t1n)),
               "chain: null pointer (every convolution carries folded-BN bias and filter scales)");
   const bool has_c2 = d->w2 != nullptr;
   FCP_REQUIRE(!has_c2 || (d->ws2 && d->b2), "chain: conv2 needs its scales and bias");
@@ -968,7 +982,8 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
                     : (!has_c2 && d->c == 128 && d->nout == 256 && !d->res && d->cn == 64) ? 4
                     : (!has_c2 && d->c == 256 && d->nout == 1024 && d->res && d->cn == 256) ? 5
                     : (!has_c2 && d->c == 128 && d->nout == 512 && d->res && d->cn == 256) ? 6
-                    : (!has_c2 && d->t1b && d->c == 384 && d->cb == 256 && d->nout == 512 && !d->res && d->cn == 128) ? 7 : 0;
+                    : (!has_c2 && d->t1b && d->c == 384 && d->cb == 256 && d->nout == 512 && !d->res && d->cn == 128) ? 7
+                    : (!has_c2 && !d->t1b && d->c == 256 && d->nout == 1024 && d->res && d->cn == 0 && !d->w1n) ? 8 : 0;
   FCP_REQUIRE(variant == 7 || !d->t1b, "chain: a second source (t1b) exists for the two-source pair form only (c 384 = 128 + 256, nout 512, cn 128)");
   FCP_REQUIRE(variant != 0, "chain: unsupported shape (c %d, conv2 %d, nout %d, residual %d, cn %d)", d->c, (int)has_c2, d->nout,
               d->res != nullptr, d->cn);
@@ -976,9 +991,9 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   const long M = (long)d->n * d->h * d->w;
   FCP_REQUIRE(M < (1L << 31), "chain: too many pixels");
   auto aligned = [](const void* p, int ld) { return ((uintptr_t)p & 127) == 0 && ld % 32 == 0; };
-  FCP_REQUIRE(aligned(d->t1, d->t1_ld) && (!d->res || aligned(d->res, d->res_ld)) && aligned(d->out, d->out_ld) && aligned(d->t1n, d->t1n_ld),
+  FCP_REQUIRE(aligned(d->t1, d->t1_ld) && (!d->res || aligned(d->res, d->res_ld)) && aligned(d->out, d->out_ld) && (!has_p3 || aligned(d->t1n, d->t1n_ld)),
               "chain: tensors are split32 views: 128-byte aligned, channel stride a multiple of 32");
-  FCP_REQUIRE(d->t1_ld >= d->c - (d->t1b ? d->cb : 0) && (!d->res || d->res_ld >= d->nout) && d->out_ld >= d->nout && d->t1n_ld >= d->cn, "chain: channel strides too small");
+  FCP_REQUIRE(d->t1_ld >= d->c - (d->t1b ? d->cb : 0) && (!d->res || d->res_ld >= d->nout) && d->out_ld >= d->nout && (!has_p3 || d->t1n_ld >= d->cn), "chain: channel strides too small");
   const unsigned long t1_bytes = (unsigned long)M * d->t1_ld * 4ul;
   FCP_REQUIRE(t1_bytes < 0xFFFFFFF0ul, "chain: t1 must be below 4 GiB");
   ChainK k;
@@ -989,7 +1004,7 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
   const unsigned long out_bytes = (unsigned long)M * d->out_ld * 4ul;
   FCP_REQUIRE(out_bytes < 0xFFFFFFF0ul, "chain: out must span less than 4 GiB");
   k.out_bytes = (unsigned)out_bytes;
-  k.w1n = reinterpret_cast<const float*>(d->w1n); k.w1n_bytes = (unsigned)(fcp_cdiv(d->cn, 128) * 128 * d->nout * 4); k.ws1n = d->ws1n; k.b1n = d->b1n;
+  k.w1n = reinterpret_cast<const float*>(d->w1n); k.w1n_bytes = has_p3 ? (unsigned)(fcp_cdiv(d->cn, 128) * 128 * d->nout * 4) : 0u; k.ws1n = d->ws1n; k.b1n = d->b1n;
   k.t1n = d->t1n; k.t1n_ld = d->t1n_ld;
   k.n = d->n; k.h = d->h; k.w = d->w; k.M = (int)M;
   static const int nt_env = getenv("FCP_NT_STORE") ? atoi(getenv("FCP_NT_STORE")) : 1;
@@ -1022,6 +1037,7 @@ extern "C" int fcp_bottleneck_chain_f16x3(const fcp_chain_desc* d, fcp_stream_t 
     case 5: return launch<256, 256, 1024, false, true, 128>(k, s);
     case 6: return launch<256, 128, 512, false, true, 128>(k, s);     // CN = 256: 128 accumulator registers, one wave per SIMD only
     case 7: return launch<128, 384, 512, false, false, 128, false, 256>(k, s);   // [conv2 out 128 | x(::2, ::2) 256] -> 512 -> 128
+    case 8: return launch<0, 256, 1024, false, true, 128>(k, s);                  // expand form: conv3 256 -> 1024 + identity, no conv1'
     default: return big ? launch<64, 128, 256, false, false, 256>(k, s) : launch<64, 128, 256, false, false, 128>(k, s);
   }
 }

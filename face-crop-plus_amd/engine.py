@@ -618,7 +618,7 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
     return out
 
 
-def chain_supported(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, residual: bool = True, cb: int = 0) -> bool:
+def chain_supported(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv | None, residual: bool = True, cb: int = 0) -> bool:
     """Shapes ``fcp_bottleneck_chain_f16x3`` covers, all packed for the fp16x3 path with folded-BN bias:
     * with conv2: 64-wide bottleneck (3x3 64->64 / 1, 1x1 64->256 + residual), next conv1 1x1 256 -> 64 | 128;
     * pair (``pc2`` None): 1x1 128->512 + residual, next conv1 512->128 | 256  (layer-2 identity blocks; the last one
@@ -626,11 +626,15 @@ def chain_supported(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, r
       1x1 256->1024 + residual, next conv1 1024->256  (layer-3 identity blocks), or
       1x1 128->256 without residual, next conv1 256->64  (layer1.0's conv3 + downsample K-concat, layer1.1.conv1);
     * two-source pair (``cb`` = channels of the second source): 1x1 (128 + 256)->512 without residual, next conv1 512->128
-      (layer2.0's conv3 + stride-2 downsample over [conv2 out | x(::2, ::2)], layer2.1.conv1)."""
+      (layer2.0's conv3 + stride-2 downsample over [conv2 out | x(::2, ::2)], layer2.1.conv1);
+    * expand form (``pc1n`` None): 1x1 256->1024 + residual alone — conv3 + identity of a layer-3 block with its operand
+      fragments in registers and two workgroups per CU; the next conv1 is then an ordinary launch."""
     convs = [pc for pc in (pc2, pc3, pc1n) if pc is not None]
     if not all(pc.precision == 1 and pc.bias is not None and not pc.cin4 for pc in convs):
         return False
     one = lambda pc, cin, cout: (pc.cin, pc.cout, pc.kh, pc.kw, pc.stride, pc.pad) == (cin, cout, 1, 1, 1, 0)
+    if pc1n is None:          # expand form: conv3 + identity only (1x1 256 -> 1024 + residual; layer 3), no next conv1
+        return pc2 is None and residual and not cb and one(pc3, 256, 1024)
     if cb:
         return pc2 is None and not residual and cb == 256 and one(pc3, 384, 512) and one(pc1n, 512, 128) and CHAIN_TWO_SOURCE
     if pc2 is not None:
@@ -651,6 +655,11 @@ CHAIN_PATCH = os.environ.get("FCP_CHAIN_PATCH", "1") != "0"
 CHAIN_SPARSE_OUT = os.environ.get("FCP_CHAIN_SPARSE_OUT", "1") != "0"
 # layer2.0's two-source conv3 (+ downsample) and layer2.1.conv1 as one pair launch (A/B switch: 0 = the two conv launches)
 CHAIN_TWO_SOURCE = os.environ.get("FCP_CHAIN_TWO_SOURCE", "1") != "0"
+# layer-3 identity blocks: "pair-only" (default) = conv3 + identity + next conv1 in one launch (one wave per SIMD), the stand-alone
+# layer3.5.conv3 on the tuned conv tile; "pair" = the same, layer3.5.conv3 on the expand form; "expand" = every conv3 + identity on
+# the expand form (two workgroups per CU) followed by an ordinary conv1 launch.  Same bits; a three-way tie in the in-call A/B
+# (profiles/r05_probes.md section 10), so the product keeps the launch mix its profiles were taken with.
+L3_FORM = os.environ.get("FCP_L3_FORM", "pair-only")
 
 
 def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, t1: Act, res: Act | None,
@@ -666,6 +675,8 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
     what ``conv(..., x2=, x2_stride=)`` does for the stand-alone two-source conv."""
     cb = t1b.c if t1b is not None else 0
     assert chain_supported(pc2, pc3, pc1n, res is not None, cb), "bottleneck_chain: unsupported shapes"
+    if pc1n is None:
+        return _expand_conv3(pc3, t1, res, out)
     assert t1.fmt == 1 and t1.c + cb == pc3.cin and (res is None or (res.fmt == 1 and res.c == pc3.cout))
     assert t1b is None or (t1b.fmt == 1 and t1b.n == t1.n and (t1.h - 1) * t1b_stride < t1b.h and (t1.w - 1) * t1b_stride < t1b.w)
     assert res is None or (t1.n, t1.h, t1.w) == (res.n, res.h, res.w)
@@ -718,6 +729,37 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
     if RangeMonitor.active is not None:
         _monitor(f"chain {'3x3 ' if pc2 is not None else ''}{pc3.cin}->{pc3.cout}->{pc1n.cout} @{t1.h}x{t1.w}", out, t1n)
     return out, t1n
+
+
+def _expand_conv3(pc3: PackedConv, t1: Act, res: Act, out: Act | None):
+    """The expand form of ``fcp_bottleneck_chain_f16x3`` (cn = 0, no conv1' filter): out = relu(conv3(t1) + res), bit-identical to
+    ``conv(pc3, t1, act_slope=0, res1=res, res1_pre=True, out_fmt=1)``.  Returns (out, None)."""
+    assert t1.fmt == 1 and res is not None and res.fmt == 1 and (t1.n, t1.h, t1.w) == (res.n, res.h, res.w)
+    m = t1.n * t1.h * t1.w
+    if out is None:
+        out = Act.empty(t1.n, t1.h, t1.w, pc3.cout, t1.buf.device, 1)
+    assert out.fmt == 1 and (out.n, out.h, out.w, out.c) == (t1.n, t1.h, t1.w, pc3.cout)
+    timing = ConvStats.timing
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    d = N.ChainDesc()
+    d.t1, d.res, d.out = t1.ptr(), res.ptr(), out.ptr()
+    d.w3, d.ws3, d.b3 = N.ptr(pc3.w), N.ptr(pc3.wscale), N.ptr(pc3.bias)
+    d.n, d.h, d.w, d.c, d.cn, d.nout = t1.n, t1.h, t1.w, pc3.cin, 0, pc3.cout
+    d.t1_ld, d.res_ld, d.out_ld = t1.ld, res.ld, out.ld
+    N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
+    flops = pc3.flops_per_pixel * m
+    if timing is not None:
+        e1.record()
+        timing.append((e0, e1, flops, f"expand {pc3.cin}->{pc3.cout} @{t1.h}x{t1.w} +res",
+                       4 * (m * (pc3.cin + 2 * pc3.cout) + pc3.cin * pc3.cout)))
+    if ConvStats.enabled:
+        ConvStats.flops += flops
+        ConvStats.launches += 1
+    if RangeMonitor.active is not None:
+        _monitor(f"expand {pc3.cin}->{pc3.cout} @{t1.h}x{t1.w}", out)
+    return out, None
 
 
 def u8_to_nhwc4(images_u8: torch.Tensor, sub=(0.0, 0.0, 0.0), div: float = 1.0) -> Act:

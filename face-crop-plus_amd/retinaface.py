@@ -232,6 +232,12 @@ class RetinaFace:
                     feats.append(x)
                 continue
             o = E.conv(blk["c2"], o, act_slope=0.0, out_fmt=f)
+            if chain and blk["ds"] is None and E.chain_supported(None, blk["c3"], None) and (
+                    E.L3_FORM == "expand" or (E.L3_FORM == "pair" and (nxt is None or not E.chain_supported(None, blk["c3"], nxt["c1"])))):
+                x, _ = E.bottleneck_chain(None, blk["c3"], None, o, x)       # conv3 + identity on the expand form; conv1 follows as a launch
+                if blk["feat"]:
+                    feats.append(x)
+                continue
             if (chain and blk["ds"] is None and nxt is not None and E.chain_supported(None, blk["c3"], nxt["c1"])):
                 x, pre = E.bottleneck_chain(None, blk["c3"], nxt["c1"], o, x)          # conv3 (+ identity) + next conv1 (layers 2-3)
                 if blk["feat"]:

@@ -223,3 +223,35 @@ def test_two_source_pair_equals_the_two_convs(n, h, w, device):
     if h > 1:
         with pytest.raises(RuntimeError, match="t1b"):
             N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 20, 24), (1, 7, 5), (3, 33, 41), (4, 40, 40), (1, 1, 1)])
+def test_expand_form_equals_the_conv(n, h, w, device):
+    """Round 5: conv3 + identity of a layer-3 block alone (1x1 256 -> 1024 + residual, ReLU) on the expand form of the chain
+    kernel — operand fragments straight from global memory into registers, filters streamed through LDS, two workgroups per CU,
+    no conv1' — is bit-identical to the stand-alone convolution with the fused residual epilogue, ragged tiles and channel-slice
+    views included."""
+    from face_crop_plus_amd import engine as E
+    g = torch.Generator().manual_seed(n * 10 + w)
+    t = F.relu(torch.randn(n, 256, h, w, generator=g))
+    x = F.relu(torch.randn(n, 1024, h, w, generator=g))
+    w3 = torch.randn(1024, 256, 1, 1, generator=g) * (2 / 256) ** 0.5
+    bn3 = _bn(1024, g)
+    with E.default_precision("f16x3"):
+        pc3 = E.pack_conv(w3, None, bn3, 1, 0, device)
+    assert E.chain_supported(None, pc3, None)
+    nhwc = lambda a: a.permute(0, 2, 3, 1).contiguous().to(device)
+    ta, xa = E.f32_to_split32(E.Act(nhwc(t))), E.f32_to_split32(E.Act(nhwc(x)))
+    ref = E.conv(pc3, ta, act_slope=0.0, res1=xa, res1_pre=True, out_fmt=1)
+    out, none = E.bottleneck_chain(None, pc3, None, ta, xa)
+    torch.cuda.synchronize()
+    assert none is None and torch.equal(out.buf, ref.buf)
+    again, _ = E.bottleneck_chain(None, pc3, None, ta, xa)
+    assert torch.equal(again.buf, out.buf)
+    r = F.relu(_ref_bn(F.conv2d(t, w3), bn3) + x)
+    assert (out.nchw().cpu() - r).abs().max().item() <= 3e-5 * float(r.abs().max()) + 1e-6
+    wide_t, wide_o = E.Act.empty(n, h, w, 320, device, 1), E.Act.empty(n, h, w, 1088, device, 1)
+    wide_t.buf.copy_(torch.randn_like(wide_t.buf)); wide_o.buf.zero_()
+    wide_t.buf[..., 32:288].copy_(ta.buf)
+    E.bottleneck_chain(None, pc3, None, wide_t.slice(32, 256), xa, out=wide_o.slice(64, 1024))
+    assert torch.equal(wide_o.buf[..., 64:], out.buf) and wide_o.buf[..., :64].abs().max().item() == 0
