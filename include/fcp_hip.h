@@ -161,6 +161,11 @@ int fcp_conv2d_nhwc_f32(const fcp_conv_desc* desc, fcp_stream_t stream);
  *                                                 resolution)], + layer2.1.conv1: the 512-channel block output is written once
  *                                                 and not read back by a separate conv1 launch.  The operand fragments are
  *                                                 loaded straight from the two tensors (no LDS tile).
+ *   c = 256, nout = 1024, res != NULL, cn = 0,    w1n == ws1n == b1n == t1n == NULL (round 5): the EXPAND form — conv3 + identity of
+ *                                                 a layer-3 block alone, out = relu(conv3(t1) * ws3 + b3 + res), no conv1';
+ *                                                 fragments from global memory, two workgroups per CU; bit-identical to
+ *                                                 fcp_conv2d_nhwc_f32 with the fused residual epilogue (a tie with it and with the
+ *                                                 pair in the A/B: opt-in).
  * ------------------------------------------------------------------------ */
 typedef struct fcp_chain_desc {
   const float* t1;    /* conv2's input: c channels */
