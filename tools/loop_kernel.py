@@ -1,5 +1,5 @@
 """Run ONE conv-engine launch in a loop for ~N seconds (power / clock sampling with tools/smi_sample.sh).
-    python tools/loop_kernel.py chain|pair2|pair3|big3x3|big1x1|dma1x1|dma3x3s2|halo|wide|stem|copy [seconds]"""
+    python tools/loop_kernel.py chain|pair2|pair3|expand3|big1x1res|pair2s|c3ds|big3x3|big1x1|dma1x1|dma3x3s2|halo|wide|stem|copy [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -50,6 +50,16 @@ elif what == "stem":         # uint8 -> stem conv + pool + layer1.0.conv1
     imgs = torch.randint(0, 256, (b, 640, 640, 3), generator=g, dtype=torch.uint8).to(dev)
     o = E.Act.empty(b, 160, 160, 64, dev, 1); t1 = E.Act.empty(b, 160, 160, 64, dev, 1)
     f = lambda: E.stem_relu_pool_u8(ps, imgs, o, conv1=c1, t1=t1)
+elif what in ("expand3", "big1x1res"):   # conv3 + identity of a layer-3 block alone: the expand form / the 256-row kernel
+    pc3 = mk(1024, 256, 1); t, x = sp(b, 40, 256), sp(b, 40, 1024); out = E.Act.empty(b, 40, 40, 1024, dev, 1)
+    f = (lambda: E.bottleneck_chain(None, pc3, None, t, x, out)) if what == "expand3" else \
+        (lambda: E.conv(pc3, t, out, act_slope=0.0, res1=x, res1_pre=True, tile_m=256, tile_n=256, balance_tail=True))
+elif what in ("pair2s", "c3ds"):         # layer2.0: two-source conv3 + downsample (+ layer2.1.conv1 in the pair form)
+    pc3, pc1 = mk(512, 384, 1), mk(128, 512, 1)
+    t, xb = sp(b, 80, 128), sp(b, 160, 256)
+    out, t1n = E.Act.empty(b, 80, 80, 512, dev, 1), E.Act.empty(b, 80, 80, 128, dev, 1)
+    f = (lambda: E.bottleneck_chain(None, pc3, pc1, t, None, out, t1n, t1b=xb, t1b_stride=2)) if what == "pair2s" else \
+        (lambda: E.conv(pc3, t, out, act_slope=0.0, x2=xb, x2_stride=2, tile_m=256, tile_n=256))
 elif what == "copy":
     a = torch.empty(1 << 28, device=dev); c = torch.empty_like(a)
     f = lambda: c.copy_(a)

@@ -7,7 +7,7 @@ for k in $1; do
   sleep 2.5
   S=""
   for i in 1 2 3 4; do
-    S="$S | $(/opt/rocm/bin/rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" | sed -E 's/.*\(([0-9]+Mhz)\).*/\1/; s/.*Power \(W\): ([0-9.]+).*/\1 W/' | tr '\n' ' ')"
+    S="$S | $(/opt/rocm/bin/rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power \(W\)|Power:" | grep -oE "\([0-9]+Mhz\)|[0-9]+\.[0-9]+ ?W?$" | tr -d '()' | tr '\n' ' ')"
     sleep 0.4
   done
   wait $PID
