@@ -580,34 +580,37 @@ def main():
             # `hbm_kernels`): kernel -> [us per launch, algorithmic GB/s, fraction of the 8 TB/s peak]
             roofline["hbm_bound_kernels"] = {k: [v["avg_launch_us"], v["achieved"], v["frac"]] for k, v in hbm_kernels.items()
                                              if isinstance(v, dict) and "achieved" in v}
-        if extra is not None:
-            line["extra"] = extra
-            # the north-star geometry (batch 32 @1024^2, detect + align + crop: the per-GPU rate that decides >= 10 k
-            # faces/s on 8 GPUs) also inside `config`, which every consumer of the line keeps
-            ns = extra.get("c3_detect_align_crop_1024", {})
-            if "value" in ns:
-                line["config"]["north_star_geometry"] = {
-                    "workload": ns["workload"], "value": ns["value"], "unit": ns["unit"], "ms_per_step": ns["ms_per_step"],
-                    "steps": ns["steps"], "warmup": ns["warmup"], "roofline_frac": ns["roofline"]["frac"],
-                    "roofline_frac_timed": ns["roofline"].get("frac_timed")}
-                # ... and as scalars (consumers that flatten nested records keep scalars only): the north-star metric
-                # "faces/sec on synthetic 1024x1024 RGB batches" (batch 32, detect + align + crop, one GPU)
-                for where in (line["roofline"], line["config"]):
-                    where["north_star_geometry_value"] = ns["value"]
-                    where["north_star_geometry_unit"] = "faces/s, batch 32 @1024x1024, detect+align+crop, 1 GPU"
-                    where["north_star_geometry_ms_per_step"] = ns["ms_per_step"]
-                    where["north_star_geometry_steps"] = ns["steps"]
-                    where["north_star_geometry_frac"] = ns["roofline"]["frac"]
-                    where["north_star_geometry_frac_timed"] = ns["roofline"].get("frac_timed")
-        # Key order: the contract's scalar fields first (the line starts with {"metric": ...), the long side records in the
-        # middle, `config` / `roofline` / `cpu_baseline` last — a consumer that keeps only the tail of the line still sees the
-        # workload, the roofline and the north-star record
-        last = [k for k in ("config", "roofline", "cpu_baseline") if k in line]
-        line = {**{k: v for k, v in line.items() if k not in last}, **{k: line[k] for k in last}}
-        assert next(iter(line)) == "metric"
+        line = finalize_line(line, extra)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def finalize_line(line, extra):
+    """Attach the `extra` records, lift the north-star record (batch 32 @1024^2, detect + align + crop: the per-GPU rate that
+    decides >= 10 k faces/s on 8 GPUs) into `config` / `roofline` — nested, and as scalars for consumers that flatten nested
+    records — and fix the key order: the contract's scalar fields first (the line starts with {"metric": ...), the long side
+    records in the middle, `config` / `roofline` / `cpu_baseline` last, so that a consumer that keeps only the tail of the line
+    still sees the workload, the roofline and the north-star record."""
+    if extra is not None:
+        line["extra"] = extra
+        ns = extra.get("c3_detect_align_crop_1024", {})
+        if "value" in ns:
+            line["config"]["north_star_geometry"] = {
+                "workload": ns["workload"], "value": ns["value"], "unit": ns["unit"], "ms_per_step": ns["ms_per_step"],
+                "steps": ns["steps"], "warmup": ns["warmup"], "roofline_frac": ns["roofline"]["frac"],
+                "roofline_frac_timed": ns["roofline"].get("frac_timed")}
+            for where in (line["roofline"], line["config"]):
+                where["north_star_geometry_value"] = ns["value"]
+                where["north_star_geometry_unit"] = "faces/s, batch 32 @1024x1024, detect+align+crop, 1 GPU"
+                where["north_star_geometry_ms_per_step"] = ns["ms_per_step"]
+                where["north_star_geometry_steps"] = ns["steps"]
+                where["north_star_geometry_frac"] = ns["roofline"]["frac"]
+                where["north_star_geometry_frac_timed"] = ns["roofline"].get("frac_timed")
+    last = [k for k in ("config", "roofline", "cpu_baseline") if k in line]
+    line = {**{k: v for k, v in line.items() if k not in last}, **{k: line[k] for k in last}}
+    assert next(iter(line)) == "metric"
+    return line
 
 
 def self_launch(n):

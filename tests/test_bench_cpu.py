@@ -111,3 +111,28 @@ def test_cpu_baseline_host_description():
     import bench
     assert isinstance(bench.cpu_model(), str) and bench.cpu_model()
     assert 1 <= bench.host_cores() <= (os.cpu_count() or 1)
+
+
+def test_bench_line_shape_for_consumers_that_flatten_or_keep_the_tail():
+    """The JSON line must start with the contract's {"metric": ...}, end with config / roofline / cpu_baseline, and carry the
+    north-star record (batch 32 @1024^2) as scalars inside `roofline` and `config` (a parser that drops nested records keeps them)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    line = {"metric": "faces/sec end-to-end (detect+align+crop)", "value": 3500.0, "unit": "faces/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+            "ms_per_step": 18.0, "config": {"workload": "w"}, "roofline": {"frac": 0.12}, "hbm_kernels": {"k": {"x" * 50: 1}},
+            "cpu_baseline": {"value": 2.3}, "parity_check": {"faces": 32}}
+    extra = {"c3_detect_align_crop_1024": {"workload": "n", "value": 1380.0, "unit": "faces/s", "ms_per_step": 23.2, "steps": 10, "warmup": 3,
+                                            "roofline": {"frac": 0.1326, "frac_timed": 0.125}},
+             "c3_full_no_enhance": {"error": "x"}}
+    out = bench.finalize_line(line, extra)
+    keys = list(out)
+    assert keys[0] == "metric" and keys[-3:] == ["config", "roofline", "cpu_baseline"] and "extra" in keys[:-3]
+    text = json.dumps(out)
+    assert text.startswith('{"metric"')
+    for where in ("roofline", "config"):
+        assert out[where]["north_star_geometry_value"] == 1380.0 and out[where]["north_star_geometry_frac"] == 0.1326
+        assert out[where]["north_star_geometry_ms_per_step"] == 23.2 and out[where]["north_star_geometry_steps"] == 10
+    assert text.rindex('"north_star_geometry_value"') > text.rindex('"hbm_kernels"')      # visible in the tail
+    plain = bench.finalize_line({"metric": "m", "value": 1.0, "config": {}, "roofline": {}}, None)   # --no-extra: nothing to lift
+    assert list(plain) == ["metric", "value", "config", "roofline"]
