@@ -132,11 +132,17 @@ class _Worker:
         self.seq = 0
         self.given_back = 0
 
-    def _reply(self):
+    def _io(self, fn, *args):
+        """Every socket operation of the parent goes through here: whichever side of a request the worker's death falls on —
+        the send (``BrokenPipeError`` / ``ConnectionResetError``), the reply (``EOFError``) or a payload that follows it — the
+        caller sees the one documented error."""
         try:
-            rep = self.conn.recv()
+            return fn(*args)
         except (EOFError, OSError) as e:
             raise RuntimeError(f"I/O worker process {self.proc.pid} died ({type(e).__name__})") from e
+
+    def _reply(self):
+        rep = self._io(self.conn.recv)
         if rep[0] == "error":
             raise RuntimeError(f"I/O worker: {rep[1]}")
         return rep
@@ -144,7 +150,7 @@ class _Worker:
     def read_many(self, paths):
         """-> [(RGB uint8 HWC array or None, release token or None)] in the order of ``paths``: one request, one reply.
         Warnings of the decoder are re-issued here."""
-        self.conn.send(("read", list(paths)))
+        self._io(self.conn.send, ("read", list(paths)))
         out = []
         for rep in self._reply()[1]:
             for note in rep[-1]:
@@ -163,7 +169,7 @@ class _Worker:
         for k, (shape, tok) in enumerate(out):
             if tok == "pipe":
                 buf = bytearray(int(np.prod(shape)))
-                self.conn.recv_bytes_into(buf)
+                self._io(self.conn.recv_bytes_into, buf)
                 out[k] = (np.frombuffer(buf, dtype=np.uint8).reshape(shape), None)
         return out
 
@@ -186,8 +192,8 @@ class _Worker:
 
     def write(self, path, pixels: np.ndarray) -> bool:
         pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
-        self.conn.send(("write", path, pixels.shape))
-        self.conn.send_bytes(memoryview(pixels).cast("B"))
+        self._io(self.conn.send, ("write", path, pixels.shape))
+        self._io(self.conn.send_bytes, memoryview(pixels).cast("B"))
         rep = self._reply()
         for note in rep[2]:
             warnings.warn(note)

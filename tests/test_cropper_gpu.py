@@ -66,19 +66,48 @@ def test_process_dir_all_strategy_groups_and_masks(image_dir, tmp_path, device):
 
 
 def test_given_landmarks_and_enhancement(image_dir, tmp_path, device):
-    """Pre-computed landmark path (no detector) + RRDB enhancement of every image (landmarks=None rule)."""
-    from face_crop_plus_amd import Cropper
+    """Pre-computed landmark path (no detector, cropper.py:796-813) WITH RRDB enhancement switched on (cropper.py:833-836):
+    the gate of rrdb.py:124-140 measures each image's faces against the area of images[0]; the threshold sits between
+    the two face factors, so exactly one of the two images is enhanced.  Checked against the oracle: the gate decision,
+    the enhanced image (rounding-boundary flips only) and the written crops (byte-equal to the oracle's estimate + warp of
+    the enhanced / untouched image)."""
+    from PIL import Image
+    from face_crop_plus_amd import Cropper, weights
+    from oracle import rrdb_ref as RR
     tgt = A.landmarks_target((48, 48), 0.65)
     lms = np.stack([tgt * 1.5 + 10, tgt * 1.2 + 20]).astype(np.float32)
     names = np.array(["000000.png", "000003.png"])
+    sd = weights.generate_state_dict("rrdb")
+    # face factors as the reference computes them: (x4-x0)(y4-y0) / (H0*W0) with images[0] = 000000.png (160x160)
+    ff = [float((l[4, 0] - l[0, 0]) * (l[4, 1] - l[0, 1]) / (160 * 160)) for l in lms]
+    assert ff[1] < ff[0]
+    thr = 0.5 * (ff[0] + ff[1])
     out = tmp_path / "given"
-    c = Cropper(output_size=48, landmarks=(lms, names), det_threshold=None, padding="reflect", device="cuda:0")
+    c = Cropper(output_size=48, landmarks=(lms, names), det_threshold=None, enh_threshold=thr, padding="reflect",
+                device="cuda:0", weights={"rrdb": sd})
+    assert c.enh_model is not None
     c.process_dir(image_dir, str(out), desc=None)
     assert sorted(os.listdir(out)) == ["000000.png", "000003.png"]
-    from PIL import Image
-    src = np.asarray(Image.open(os.path.join(image_dir, "000003.png")).convert("RGB"))
-    exp = A.warp_affine(src, A.estimate_transform(lms[1], tgt), (48, 48), A.BORDER["reflect"])
-    assert np.array_equal(np.asarray(Image.open(out / "000003.png").convert("RGB")), exp)
+    files = sorted(f for f in os.listdir(image_dir) if f != "broken.png")
+    imgs = [np.asarray(Image.open(os.path.join(image_dir, f)).convert("RGB")) for f in files]
+    indices = [0, 3]                                             # batch order: the two files that have a landmark row
+    assert RR.gate(lms, indices, len(imgs), 160, 160, thr) == [False, False, False, True, False]
+    assert c.enh_model.gate(len(imgs), 160, 160, lms, indices) == [3]
+    # image 0: below the gate -> the plain warp of the decoded file
+    exp0 = A.warp_affine(imgs[0], A.estimate_transform(lms[0], tgt), (48, 48), A.BORDER["reflect"])
+    assert np.array_equal(np.asarray(Image.open(out / "000000.png").convert("RGB")), exp0)
+    # image 3 (200x100): enhanced.  GPU enhancer vs the oracle's predict on the same pixels ...
+    x = torch.from_numpy(imgs[3])[None]
+    ref = RR.predict(x.permute(0, 3, 1, 2).float(), sd, None, None).permute(0, 2, 3, 1).numpy()[0]
+    enh = c.enh_model.predict(x.to(c.device), None, None)[0].cpu().numpy()
+    diff = np.abs(enh.astype(int) - ref.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3 and not np.array_equal(enh, imgs[3])
+    # ... and the written crop is the oracle's warp of that enhanced image, byte for byte
+    exp3 = A.warp_affine(enh, A.estimate_transform(lms[1], tgt), (48, 48), A.BORDER["reflect"])
+    got3 = np.asarray(Image.open(out / "000003.png").convert("RGB"))
+    assert np.array_equal(got3, exp3)
+    plain3 = A.warp_affine(imgs[3], A.estimate_transform(lms[1], tgt), (48, 48), A.BORDER["reflect"])
+    assert not np.array_equal(got3, plain3)                        # the enhancement really reached the file
 
 
 def test_crop_align_numpy_signature(device):
@@ -319,16 +348,38 @@ def test_process_dir_recovers_after_a_decode_worker_dies(image_dir, tmp_path, de
         pool2 = c._io_procs
         real = pool2.read_many
 
-        def dying(paths):
+        def dying(paths):                                        # dead AND reaped before the request: the send fails
             for w in pool2._readers:
                 w.proc.kill()
+                w.proc.wait(timeout=5)
             return real(paths)
         pool2.read_many = dying
         with pytest.raises(RuntimeError, match="I/O worker process"):
             c.process_dir(image_dir, str(tmp_path / "broken"), desc=None)
         assert c._io_procs is None and pool2.closed
         c.process_dir(image_dir, str(tmp_path / "third"), desc=None)
+        # the opposite ordering: the worker dies with the request already queued (stopped first, killed after the send) —
+        # the failure then comes from the reply, and must be the same error
+        import signal
+        import threading
+        pool3 = c._io_procs
+        real3, timers = pool3.read_many, []
+
+        def dying_after_send(paths):
+            for w in pool3._readers:
+                if w.proc.poll() is None:
+                    os.kill(w.proc.pid, signal.SIGSTOP)
+                    timers.append(threading.Timer(0.3, w.proc.kill))
+                    timers[-1].start()
+            return real3(paths)
+        pool3.read_many = dying_after_send
+        with pytest.raises(RuntimeError, match="I/O worker process"):
+            c.process_dir(image_dir, str(tmp_path / "broken2"), desc=None)
+        for t in timers:
+            t.join()
+        assert c._io_procs is None and pool3.closed
+        c.process_dir(image_dir, str(tmp_path / "fourth"), desc=None)
     ref = sorted(os.listdir(tmp_path / "first"))
-    assert ref and sorted(os.listdir(tmp_path / "second")) == ref and sorted(os.listdir(tmp_path / "third")) == ref
+    assert ref and all(sorted(os.listdir(tmp_path / d)) == ref for d in ("second", "third", "fourth"))
     for f in ref:
-        assert (tmp_path / "first" / f).read_bytes() == (tmp_path / "third" / f).read_bytes()
+        assert (tmp_path / "first" / f).read_bytes() == (tmp_path / "third" / f).read_bytes() == (tmp_path / "fourth" / f).read_bytes()

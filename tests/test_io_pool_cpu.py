@@ -152,3 +152,41 @@ def test_unhealthy_pool_is_detected(tmp_path):
     finally:
         p.close()
     assert not p.healthy()                                          # closed
+
+
+@pytest.mark.parametrize("when", ["before_send", "between_send_and_reply"])
+@pytest.mark.parametrize("op", ["read", "write"])
+def test_worker_death_is_one_documented_error_whichever_side_it_falls_on(tmp_path, when, op):
+    """A dead worker surfaces as RuntimeError("I/O worker process <pid> died ...") from every parent-side socket operation:
+    the send (BrokenPipeError / ConnectionResetError when the process is already gone) as well as the reply (EOFError when it
+    dies with the request in its socket buffer).  Both orderings are made deterministic here: 'before' waits for the
+    process to be reaped, 'between' stops the worker (SIGSTOP), queues the request, then kills it."""
+    import signal
+    from PIL import Image
+    from face_crop_plus_amd._io_pool import IOProcesses
+    Image.fromarray(_img(32, 32, 1)).save(tmp_path / "a.png")
+    p = IOProcesses(1, 1, ring_mb=1)
+    try:
+        w = (p._readers if op == "read" else p._writers)[0]
+        call = (lambda: p.read(str(tmp_path / "a.png"))) if op == "read" else (lambda: p.write(str(tmp_path / "o.png"), _img(8, 8, 2)))
+        call()                                                      # the worker is up and serving
+        if op == "read":
+            p.release([tok for _, tok in [p.read(str(tmp_path / "a.png"))]])
+        if when == "before_send":
+            w.proc.kill()
+            w.proc.wait(timeout=5)
+            with pytest.raises(RuntimeError, match=f"I/O worker process {w.proc.pid} died"):
+                call()
+        else:
+            os.kill(w.proc.pid, signal.SIGSTOP)
+            killer = threading.Timer(0.3, w.proc.kill)              # the request is in the socket buffer by then
+            killer.start()
+            try:
+                with pytest.raises(RuntimeError, match=f"I/O worker process {w.proc.pid} died"):
+                    call()
+            finally:
+                killer.cancel()
+                w.proc.wait(timeout=5)
+        assert not p.healthy()
+    finally:
+        p.close()
