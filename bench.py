@@ -470,9 +470,10 @@ def main():
     global LAUNCH_TABLE, AUTOTUNE_ROOFLINE
     LAUNCH_TABLE = args.launch_table
     AUTOTUNE_ROOFLINE = not args.no_autotune and os.environ.get("FCP_AUTOTUNE", "1") != "0"
-    if not AUTOTUNE_ROOFLINE:
+    if args.no_autotune:
         from face_crop_plus_amd import engine as _E
         _E.Autotune.use_tables = False              # heuristic tiles: neither tuning launches nor the shipped / user tables
+                                                    # (what FCP_TUNE_TABLES=0 does; FCP_AUTOTUNE=0 alone keeps the tables)
     full = args.workload == "full"
     if args.batch is None:
         args.batch = 32 if full else 64

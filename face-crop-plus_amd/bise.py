@@ -50,12 +50,14 @@ class BiSeNet:
         N.lib()
         self.device = device
         sd = load_state_dict("bisenet", weights, device=device)
-        with torch.cuda.device(device), E.default_precision(precision):
-            self._p = self._pack(sd, device)
-        self.precision = E.resolve_precision(precision)
-        if self.precision == 1 and E.selfcheck_mode(weights):
-            self.selfcheck(sd)
+        self._repack(sd, precision)
+        E.selfcheck_at_load(self, sd, weights, precision, lambda: self._repack(sd, "f32"))
         return self
+
+    def _repack(self, sd, precision):
+        with torch.cuda.device(self.device), E.default_precision(precision):
+            self._p = self._pack(sd, self.device)
+        self.precision = E.resolve_precision(precision)
 
     @torch.no_grad()
     def selfcheck(self, sd=None, faces_u8: torch.Tensor | None = None, rel_tol: float = 1e-4):

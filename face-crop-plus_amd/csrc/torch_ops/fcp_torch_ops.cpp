@@ -130,8 +130,8 @@ void conv2d_out(const Tensor& x, int64_t x_c0, int64_t cin, const Tensor& w, con
 std::tuple<Tensor, Tensor> bottleneck_chain(const Tensor& t1, int64_t t1_c0, const c10::optional<Tensor>& res, int64_t res_c0,
                                             const c10::optional<Tensor>& w2, const c10::optional<Tensor>& ws2,
                                             const c10::optional<Tensor>& b2, const Tensor& w3, const Tensor& ws3,
-                                            const Tensor& b3, const Tensor& w1n, const Tensor& ws1n, const Tensor& b1n,
-                                            int64_t c, int64_t nout, int64_t cn, int64_t tile_m, int64_t flags,
+                                            const Tensor& b3, const c10::optional<Tensor>& w1n,
+                                            const c10::optional<Tensor>& ws1n, const c10::optional<Tensor>& b1n, int64_t c, int64_t nout, int64_t cn, int64_t tile_m, int64_t flags,
                                             const c10::optional<Tensor>& t1b, int64_t t1b_c0, int64_t cb, int64_t t1b_stride) {
   dev(t1, "t1", at::kFloat);
   FCP_DEVICE_GUARD(t1);
@@ -151,7 +151,15 @@ std::tuple<Tensor, Tensor> bottleneck_chain(const Tensor& t1, int64_t t1_c0, con
     d.w2 = w2->data_ptr(); d.ws2 = optp<float>(ws2, "ws2", at::kFloat); d.b2 = optp<float>(b2, "b2", at::kFloat);
   }
   d.w3 = w3.data_ptr(); d.ws3 = dev(ws3, "ws3", at::kFloat).data_ptr<float>(); d.b3 = dev(b3, "b3", at::kFloat).data_ptr<float>();
-  d.w1n = w1n.data_ptr(); d.ws1n = dev(ws1n, "ws1n", at::kFloat).data_ptr<float>(); d.b1n = dev(b1n, "b1n", at::kFloat).data_ptr<float>();
+  // expand form (cn == 0): conv3 + residual alone, no next conv1 — its filter is absent and t1n comes back with 0 channels
+  const bool has_next = w1n.has_value() && w1n->defined();
+  TORCH_CHECK(has_next == (cn > 0), "w1n / ws1n / b1n are given exactly when cn > 0 (cn == 0: the expand form)");
+  if (has_next) {
+    d.w1n = w1n->data_ptr(); d.ws1n = optp<float>(ws1n, "ws1n", at::kFloat); d.b1n = optp<float>(b1n, "b1n", at::kFloat);
+    TORCH_CHECK(d.ws1n && d.b1n, "ws1n and b1n accompany w1n");
+  } else {
+    d.t1n = nullptr;
+  }
   d.n = (int)t1.size(0); d.h = (int)t1.size(1); d.w = (int)t1.size(2); d.c = (int)c; d.cn = (int)cn; d.nout = (int)nout;
   d.t1_ld = (int)t1.size(3); d.out_ld = (int)nout; d.t1n_ld = (int)cn; d.tile_m = (int)tile_m; d.flags = (int)flags;
   if (two) {
@@ -308,7 +316,7 @@ TORCH_LIBRARY(fcp, m) {
         "bool cin4, int tile_m, int tile_n, Tensor? x2, int x2_c0, int cin2, int x2_stride, int flags, int cu_budget=0, int band_top=0, "
         "int band_bottom=0) -> ()");
   m.def("bottleneck_chain(Tensor t1, int t1_c0, Tensor? res, int res_c0, Tensor? w2, Tensor? ws2, Tensor? b2, Tensor w3, Tensor ws3, "
-        "Tensor b3, Tensor w1n, Tensor ws1n, Tensor b1n, int c, int nout, int cn, int tile_m=0, int flags=0, Tensor? t1b=None, "
+        "Tensor b3, Tensor? w1n, Tensor? ws1n, Tensor? b1n, int c, int nout, int cn, int tile_m=0, int flags=0, Tensor? t1b=None, "
         "int t1b_c0=0, int cb=0, int t1b_stride=1) -> (Tensor, Tensor)");
   m.def("retina_decode(Tensor head0, Tensor head1, Tensor head2, int img_h, int img_w, float vis, float var0, float var1) "
         "-> (Tensor, Tensor, Tensor, Tensor, Tensor)");

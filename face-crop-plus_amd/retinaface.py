@@ -63,16 +63,19 @@ class RetinaFace:
         N.lib()  # fail loudly now if the extension is missing
         self.device = device
         sd = load_state_dict("retinaface", weights, device=device)
-        with torch.cuda.device(device), E.default_precision(precision):
-            self._p = self._pack(sd, device)
-        self.precision = E.resolve_precision(precision)
+        self._repack(sd, precision)
         E.device_props(device)          # cached here, on the loading thread: the worker threads only ever read the cache
         # Range / accuracy guard of the fp16x3 path (``selfcheck``): FCP_SELFCHECK=1 always, 0 never; by default ("auto")
         # whenever the weights come from a checkpoint — a file, the hub cache or a download — i.e. are not this package's
-        # own generated ones or a state dict the caller built in memory.
-        if self.precision == 1 and E.selfcheck_mode(weights):
-            self.selfcheck(sd)
+        # own generated ones or a state dict the caller built in memory.  Weights the split-binary16 path cannot carry
+        # send a default-precision load to the exact-fp32 path (``E.selfcheck_at_load``).
+        E.selfcheck_at_load(self, sd, weights, precision, lambda: self._repack(sd, "f32"))
         return self
+
+    def _repack(self, sd, precision):
+        with torch.cuda.device(self.device), E.default_precision(precision):
+            self._p = self._pack(sd, self.device)
+        self.precision = E.resolve_precision(precision)
 
     @torch.no_grad()
     def selfcheck(self, sd=None, images_u8: torch.Tensor | None = None, rel_tol: float = 1e-4):

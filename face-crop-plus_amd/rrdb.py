@@ -42,6 +42,12 @@ class RRDBNet:
         N.lib()
         self.device = device
         sd = load_state_dict("rrdb", weights, device=device)
+        self._repack(sd, precision)
+        E.selfcheck_at_load(self, sd, weights, precision, lambda: self._repack(sd, "f32"))
+        return self
+
+    def _repack(self, sd, precision):
+        device = self.device
         with torch.cuda.device(device), E.default_precision(precision):
             pc = lambda k, prec=None: E.pack_conv(sd[k + ".weight"], sd[k + ".bias"], None, 1, 1, device,
                                                   precision=prec)
@@ -56,9 +62,6 @@ class RRDBNet:
                           for t in range(self.NUM_BLOCKS)]
             self._p = p
         self.precision = E.resolve_precision(precision)
-        if self.precision == 1 and E.selfcheck_mode(weights):
-            self.selfcheck(sd)
-        return self
 
     @torch.no_grad()
     def selfcheck(self, sd=None, image_u8: torch.Tensor | None = None, rel_tol: float = 1e-4):

@@ -194,6 +194,67 @@ def generate_state_dict(model: str, seed: int = 0, as_torch: bool = True):
     return out
 
 
+def trained_like_retinaface(sd, seed: int = 0, stream_gain=(10.0, 30.0, 100.0, 10.0), uniform_gain: bool = False,
+                           bn_decades: float = 1.5, outlier_fraction: float = 1e-3, outlier_scale: float = 6.0):
+    """A RetinaFace state dict with the statistics of a TRAINED checkpoint, derived from ``sd`` (normally the generated one).
+
+    The release checkpoint cannot be fetched here (no network), and what the generated weights lack is exactly what a
+    trained one has: arbitrary scales.  Three reparametrisations, all expressed on the reference's own keys:
+
+    1. every conv -> BatchNorm pair gets a per-output-channel scale s = 10^U(-d, d) (``bn_decades``): ``W[c] *= s``,
+       ``running_mean *= s``, ``running_var *= s^2`` — ``running_var`` then spans ~1e-3 ... 1e3 and the un-normalised conv
+       output the same decades, as in trained nets (exactly function-preserving but for BatchNorm's eps);
+    2. a fraction of every conv filter's entries is multiplied by ``outlier_scale`` (heavy tails; changes the function a
+       little, the oracle sees the same weights);
+    3. the residual stream of ResNet layer L is scaled per channel by k_c in [1, stream_gain[L-1]] (all channels at the
+       gain itself with ``uniform_gain``): its producers' (bn3, downsample.1) gamma and beta times k, every consumer's
+       (the following conv1 / downsample.0 / fpn.output) input channel divided by k — exactly function-preserving for
+       k > 0 since ReLU is positively homogeneous; the stream's activations reach gain x their former size.
+
+    Returns a new dict of torch tensors (``sd`` is not modified)."""
+    import torch
+    rng = np.random.default_rng(0x7A1ED + seed)
+    out = {k: torch.as_tensor(v).clone() for k, v in sd.items()}
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    pairs = [(k[:-len(".weight")], None) for k in out if k.endswith(".weight") and out[k].ndim == 4]
+    bn_of = {}
+    for conv, _ in pairs:                                      # conv name -> its BatchNorm's name
+        head, _, tail = conv.rpartition(".")
+        if tail.startswith("conv") and (head + ".bn" + tail[4:] + ".running_var") in out:
+            bn_of[conv] = head + ".bn" + tail[4:]              # body.*.convN -> bnN, body.conv1 -> body.bn1
+        elif tail == "0" and (head + ".1.running_var") in out:
+            bn_of[conv] = head + ".1"                          # downsample.0/.1, fpn.*.0/.1, ssh*.0/.1
+    for conv, bn in bn_of.items():
+        w = out[conv + ".weight"]
+        s = f32(10.0 ** rng.uniform(-bn_decades, bn_decades, w.shape[0]))
+        out[conv + ".weight"] = w * s[:, None, None, None]
+        out[bn + ".running_mean"] = out[bn + ".running_mean"] * s
+        out[bn + ".running_var"] = out[bn + ".running_var"] * s * s
+    for conv, _ in pairs:
+        w = out[conv + ".weight"]
+        hit = f32(rng.random(tuple(w.shape)) < outlier_fraction)
+        out[conv + ".weight"] = w * (1 + (outlier_scale - 1) * hit)
+    blocks = (3, 4, 6, 3)
+    for li, gain in enumerate(stream_gain, 1):
+        c = 256 * 2 ** (li - 1)
+        k = f32(np.full(c, gain) if uniform_gain else gain ** rng.uniform(0.0, 1.0, c))
+        if not uniform_gain:
+            k[rng.integers(0, c, max(1, c // 20))] = float(gain)         # a few channels sit at the gain itself
+        pre = f"body.layer{li}"
+        for b in range(blocks[li - 1]):
+            for nm in ("bn3",) + (("downsample.1",) if b == 0 else ()):
+                out[f"{pre}.{b}.{nm}.weight"] = out[f"{pre}.{b}.{nm}.weight"] * k
+                out[f"{pre}.{b}.{nm}.bias"] = out[f"{pre}.{b}.{nm}.bias"] * k
+            if b > 0:
+                out[f"{pre}.{b}.conv1.weight"] = out[f"{pre}.{b}.conv1.weight"] / k[None, :, None, None]
+        consumers = [f"body.layer{li + 1}.0.conv1", f"body.layer{li + 1}.0.downsample.0"] if li < 4 else []
+        if li >= 2:
+            consumers.append(f"fpn.output{li - 1}.0")
+        for nm in consumers:
+            out[nm + ".weight"] = out[nm + ".weight"] / k[None, :, None, None]
+    return out
+
+
 URL_ROOT = "https://github.com/mantasu/face-crop-plus/releases/download/v1.0.0/"   # reference _layers.py:13
 
 

@@ -255,3 +255,34 @@ def test_expand_form_equals_the_conv(n, h, w, device):
     wide_t.buf[..., 32:288].copy_(ta.buf)
     E.bottleneck_chain(None, pc3, None, wide_t.slice(32, 256), xa, out=wide_o.slice(64, 1024))
     assert torch.equal(wide_o.buf[..., 64:], out.buf) and wide_o.buf[..., :64].abs().max().item() == 0
+
+
+def test_expand_form_through_the_registered_op_equals_ctypes(device):
+    """FCP_BOUNDARY=torch: the expand form (no next conv1: w1n / ws1n / b1n = None, cn = 0) goes through ``fcp::bottleneck_chain``
+    like the other chain forms — same bits as the C-ABI call; giving a conv1' filter with cn = 0 (or none with cn > 0) is refused."""
+    from face_crop_plus_amd import engine as E, torch_ops as T
+    g = torch.Generator().manual_seed(77)
+    n, h, w = 2, 13, 17
+    t = F.relu(torch.randn(n, 256, h, w, generator=g))
+    x = F.relu(torch.randn(n, 1024, h, w, generator=g))
+    with E.default_precision("f16x3"):
+        pc3 = E.pack_conv(torch.randn(1024, 256, 1, 1, generator=g) * (2 / 256) ** 0.5, None, _bn(1024, g), 1, 0, device)
+    nhwc = lambda a: a.permute(0, 2, 3, 1).contiguous().to(device)
+    ta, xa = E.f32_to_split32(E.Act(nhwc(t))), E.f32_to_split32(E.Act(nhwc(x)))
+    prev, outs = T.ENABLED, {}
+    try:
+        for mode in (False, True):
+            T.ENABLED = mode
+            outs[mode], none = E.bottleneck_chain(None, pc3, None, ta, xa)
+            assert none is None
+    finally:
+        T.ENABLED = prev
+    torch.cuda.synchronize()
+    assert torch.equal(outs[False].buf, outs[True].buf)
+    ops = T.load()
+    with pytest.raises(RuntimeError, match="cn > 0"):
+        ops.bottleneck_chain(ta.buf, 0, xa.buf, 0, None, None, None, pc3.w, pc3.wscale, pc3.bias, pc3.w, pc3.wscale, pc3.bias,
+                             256, 1024, 0, 0, 0, None, 0, 0, 1)
+    with pytest.raises(RuntimeError, match="cn > 0"):
+        ops.bottleneck_chain(ta.buf, 0, xa.buf, 0, None, None, None, pc3.w, pc3.wscale, pc3.bias, None, None, None,
+                             256, 1024, 256, 0, 0, None, 0, 0, 1)

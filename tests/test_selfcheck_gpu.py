@@ -102,3 +102,77 @@ def test_selfcheck_bisenet_and_rrdb(device):
     bad["RRDB_trunk.3.RDB2.conv3.weight"] = sde["RRDB_trunk.3.RDB2.conv3.weight"] * 1e6
     with pytest.raises(FloatingPointError, match=r"RRDBNet.*2\^15"):
         RRDBNet(0.001).load(device, bad).selfcheck(bad)
+
+
+def test_selfcheck_compare_bands(monkeypatch):
+    """<= tol silent; (tol, hard] warns (raises under FCP_SELFCHECK=1); > hard or non-finite raises in every mode."""
+    import warnings
+    from face_crop_plus_amd import engine as E
+    monkeypatch.delenv("FCP_SELFCHECK", raising=False)
+    ref = torch.tensor([1.0, -2.0, 0.5])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert E.selfcheck_compare("t", ref + 1e-5, ref, 1e-4) < 1e-4
+    with pytest.warns(UserWarning, match="disagree"):
+        d = E.selfcheck_compare("t", ref + 1e-3, ref, 1e-4)
+    assert 1e-4 < d <= E.SELFCHECK_HARD_TOL
+    with pytest.raises(FloatingPointError, match="hard limit"):
+        E.selfcheck_compare("t", ref + 0.1, ref, 1e-4)
+    with pytest.raises(FloatingPointError):
+        E.selfcheck_compare("t", ref * float("nan"), ref, 1e-4)
+    monkeypatch.setenv("FCP_SELFCHECK", "1")
+    with pytest.raises(FloatingPointError, match="disagree"):
+        E.selfcheck_compare("t", ref + 1e-3, ref, 1e-4)
+
+
+def _oracle_vs(det, sd, images_u8):
+    from oracle import retinaface_ref as R
+    lm_ref, idx_ref = R.predict(images_u8.permute(0, 3, 1, 2).float(), sd, "largest", 0.6)
+    lm, idx = det.predict(images_u8.to(det.device))
+    assert list(idx) == list(idx_ref) and len(idx) > 0
+    return float(np.abs(lm - lm_ref).max())
+
+
+def test_trained_like_checkpoint_rehearsal(device, tmp_path, monkeypatch):
+    """What a real checkpoint would do to the load path, without the checkpoint (no network here): the generated weights
+    re-parametrised to trained statistics (``weights.trained_like_retinaface``: BatchNorm running_var over six decades,
+    heavy-tailed filters, residual streams two to three decades above O(1)) go through ``load`` FROM A FILE, i.e. with the
+    automatic self-check.  In range (peak ~1e4 < 2^15): silent, fp16x3 kept, landmarks / indices equal the oracle's on
+    the same weights.  Out of range (a stream past 2^15): a default-precision load warns and lands on the exact-fp32
+    path by itself — oracle-equal results again — while an explicit precision="f16x3" and the strict mode raise."""
+    import warnings
+    from face_crop_plus_amd import weights
+    from face_crop_plus_amd.retinaface import RetinaFace
+    monkeypatch.delenv("FCP_SELFCHECK", raising=False)
+    sd = weights.generate_state_dict("retinaface")
+    g = torch.Generator().manual_seed(44)
+    imgs = torch.randint(0, 256, (3, 160, 192, 3), generator=g, dtype=torch.uint8)
+    # ---- in range
+    ok = weights.trained_like_retinaface(sd, 1, stream_gain=(10.0, 30.0, 500.0, 10.0))
+    rv = torch.cat([v.flatten() for k, v in ok.items() if k.endswith("running_var") and k != "body.bn1.running_var"])
+    assert float(rv.min()) < 2e-3 and float(rv.max()) > 5e2
+    torch.save(ok, tmp_path / "ok.pth")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                           # the guard stays silent
+        det = RetinaFace("largest", 0.6).load(device, str(tmp_path / "ok.pth"))
+    rep = det.selfcheck_report
+    peak = max(v for _, v in rep["launch_absmax"])
+    print("trained-like in range: peak |x|", peak, "head rel diff", rep["head_rel_diff"])
+    assert det.precision == 1 and 3e3 < peak < rep["limit"] and max(rep["head_rel_diff"]) < 1e-4
+    err = _oracle_vs(det, ok, imgs)
+    print("landmark err vs oracle (fp16x3, trained-like)", err)
+    assert err < 1e-3
+    # ---- out of range: layer3's stream at 4000x
+    big = weights.trained_like_retinaface(sd, 1, stream_gain=(10.0, 30.0, 4000.0, 10.0), uniform_gain=True)
+    torch.save(big, tmp_path / "big.pth")
+    with pytest.warns(RuntimeWarning, match=r"2\^15.*Falling back to precision='f32'"):
+        det32 = RetinaFace("largest", 0.6).load(device, str(tmp_path / "big.pth"))
+    assert det32.precision == 0 and det32.selfcheck_report["fallback"] == "f32" and "2^15" in det32.selfcheck_report["reason"]
+    err = _oracle_vs(det32, big, imgs)
+    print("landmark err vs oracle (fallback f32, out-of-range weights)", err)
+    assert err < 1e-3
+    with pytest.raises(FloatingPointError, match=r"2\^15"):      # asked for by name: no silent change of arithmetic
+        RetinaFace("largest", 0.6).load(device, str(tmp_path / "big.pth"), "f16x3")
+    monkeypatch.setenv("FCP_SELFCHECK", "1")
+    with pytest.raises(FloatingPointError, match=r"2\^15"):      # strict mode: an error, not a fallback
+        RetinaFace("largest", 0.6).load(device, str(tmp_path / "big.pth"))

@@ -12,6 +12,8 @@ import torch
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 BORDERS = ("constant", "replicate", "reflect", "wrap", "reflect_101")
+# |kernel - cv2| when the wheel is of the float family (see test_kernel_warp_vs_opencv): 255/32 + 2 roundings, and how many bytes
+KERNEL_VS_FLOAT_WHEEL_MAX, KERNEL_VS_FLOAT_WHEEL_FRACTION = 10, 0.5
 HOW = "run `python tools/make_cv2_fixture.py` where opencv-python / torchvision are installed and commit the file"
 
 
@@ -111,6 +113,10 @@ def test_oracle_warp_vs_opencv():
     # "fixed": byte-exact by construction of _warp_family; "float32": within one rounding of the float restatement (which is
     # written from memory of the published source: an exact match is not claimed); anything else is a defect to look at
     assert family in ("fixed", "float32"), f"neither family explains this wheel's warpAffine: {lines}"
+    # the fixture says which family it was generated as (tools/make_cv2_fixture.py records it): a regenerated fixture of the
+    # other family, or an oracle change that re-classifies the committed one, fails loudly instead of switching tolerance
+    if "warp_family" in z.files:
+        assert str(z["warp_family"]) == family, f"fixture recorded as {z['warp_family']!r}, classified as {family!r}"
     # the wheel's own portable path (optimised code switched off), when recorded, is the classic algorithm
     if "warp0_constant_noopt" in z.files:
         for k, img, mats, dsize in _warp_cases(z):
@@ -140,6 +146,12 @@ def test_kernel_warp_vs_opencv(device):
                 # distance between the two algorithms, i.e. the kernel still equals the fixed-point restatement byte for byte
                 fixed = np.stack([A.warp_affine(img, m, dsize, A.BORDER[b]) for m in mats])
                 assert np.array_equal(got, fixed), f"case {k}, border {b}"
+                # ... and that distance is BOUNDED against the wheel itself, not only explained: the fixed-point family
+                # quantises the source coordinate to 1/32 px, so on an image of grey-level range R neighbouring pixels differ by
+                # <= R and the two bilinear results by <= R/32 + 1 rounding each way (KERNEL_VS_FLOAT_WHEEL_MAX for uint8 noise);
+                # a drift of the kernel beyond it fails here even though no fixed-point wheel is at hand
+                assert mx <= KERNEL_VS_FLOAT_WHEEL_MAX and frac <= KERNEL_VS_FLOAT_WHEEL_FRACTION, \
+                    f"case {k}, border {b}: kernel vs float-family cv2: max |d| {mx}, {frac:.2e} of bytes"
             if f"warp{k}_{b}_noopt" in z.files:
                 assert np.array_equal(got, z[f"warp{k}_{b}_noopt"]), f"case {k}, border {b}: portable-path wheel output"
 

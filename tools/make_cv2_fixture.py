@@ -110,6 +110,19 @@ def make_align(cv2):
                 cv2.setUseOptimized(True)
         k += 1
     out["warp_cases"] = np.array(k)
+    # which algorithm family this wheel's warpAffine belongs to, decided against the oracle's two variants exactly as
+    # tests/test_third_party_pins.py::_warp_family does; recorded so that a later re-classification fails loudly
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import align_ref as A
+    worst = {"fixed": 0, "float32": 0}
+    for c in range(k):
+        for b in BORDERS:
+            for j, m in enumerate(out[f"warp{c}_mat"]):
+                for variant in worst:
+                    got = A.warp_affine(out[f"warp{c}_img"], m, tuple(int(v) for v in out[f"warp{c}_dsize"]), A.BORDER[b], variant=variant)
+                    worst[variant] = max(worst[variant], int(np.abs(got.astype(int) - out[f"warp{c}_{b}"][j].astype(int)).max()))
+    out["warp_family"] = np.array("fixed" if worst["fixed"] == 0 else ("float32" if worst["float32"] <= 1 else "unknown"))
+    print("warpAffine family of this wheel:", out["warp_family"], worst)
     np.savez_compressed(os.path.join(GOLDEN, "opencv_align.npz"), **out)
     print("wrote opencv_align.npz", {n: v.shape for n, v in out.items() if n.startswith("est")})
 
