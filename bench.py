@@ -7,10 +7,17 @@
 One "step" = one pass of the hot path over one synthetic batch that is already
 resident in HBM: uint8 NHWC images -> RetinaFace (MFMA convs) -> decode / NMS /
 strategy -> 5-point similarity -> warpAffine crops (uint8, on device).
-Workload at N=1 is BASELINE.json configs[1]: batch 64, 640x640, strategy
-"largest", det_threshold 0.6, output 256x256.  Multi-GPU: every rank owns an
-independent batch (weak scaling, no data-path collective); weights are
-broadcast once from rank 0 over RCCL.
+Workload at N=1 (and per rank at N>1) is the configuration north_star quotes the
+metric on: detect + align + crop on batch 32 of synthetic 1024x1024 RGB images
+(configs[3]'s per-GPU share: 256 / 8), strategy "largest", det_threshold 0.6,
+output 256x256, the detector on two HIP streams.  BASELINE configs[1] (batch 64
+@640x640) is measured in the same run and reported in `extra` and, as scalars,
+in `config` / `roofline` (`configs1_*`); `--batch 64 --size 640` makes it the
+headline.  Multi-GPU: every rank owns an independent batch (weak scaling, no
+data-path collective); weights are broadcast once from rank 0 over RCCL.
+`roofline.mean_sclk_mhz` / `mean_power_w` are sampled while the timed steps run
+(a slow box — lower clock at the socket power cap — reads differently from a
+regression).
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (conv
 engine), `cpu_baseline` (the oracle timed on the host cores) and — at N=1 —
@@ -51,12 +58,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="detect", choices=["detect", "full"],
-                    help="detect = BASELINE configs[1] (detect+align+crop, the headline metric); "
+                    help="detect = detect+align+crop (the headline metric; batch 32 @1024 = north_star's geometry, "
+                         "--batch 64 --size 640 = BASELINE configs[1]); "
                          "full = configs[2] (detect + RRDB enhance + align + BiSeNet parse, batch 32 @1024)")
     ap.add_argument("--enhance", default="all", choices=["all", "none", "rule"],
                     help="workload=full: which images go through RRDB (all / none / the reference's face-area rule)")
-    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (64 detect / 32 full)")
-    ap.add_argument("--size", type=int, default=None, help="image side (640 detect / 1024 full)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32)")
+    ap.add_argument("--size", type=int, default=None, help="image side (default 1024)")
     ap.add_argument("--out-size", type=int, default=256)
     ap.add_argument("--strategy", default="largest")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,6 +84,129 @@ def parse():
                     help="write the per-launch table of the roofline passes (label, us, TFLOP/s, algorithmic GB/s) to this file")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     return ap.parse_args()
+
+
+class Telemetry:
+    """Engine clock + socket power of one GPU sampled on a thread while a region of the benchmark runs, so that a reader of
+    the line can tell a slow box (low clock at the power cap, a lower cap) from a regression without opening profiles/.
+    Sources, first that works: the amdsmi Python binding of the ROCm image; the amdgpu hwmon files in sysfs
+    (power1_input | power1_average in uW, freq1_input in Hz).  Nothing here touches the data path; every failure degrades to
+    ``{"source": None}``."""
+
+    def __init__(self, device_index=0, period_s=0.01):
+        import threading
+        self.period, self.samples, self._stop, self._thread = period_s, [], threading.Event(), None
+        self.source, self._read, self.cap_w = None, None, None
+        try:
+            self._init_amdsmi(device_index)
+        except Exception:
+            try:
+                self._init_sysfs(device_index)
+            except Exception:
+                self.source = None
+
+    @staticmethod
+    def _bdf(device_index):
+        pr = torch.cuda.get_device_properties(device_index)
+        return f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+
+    def _init_amdsmi(self, device_index):
+        import amdsmi
+        amdsmi.amdsmi_init()
+        handles = amdsmi.amdsmi_get_processor_handles()
+        h = handles[0]
+        try:                                              # several GPUs: the one torch calls `device_index`, by PCI address
+            want = self._bdf(device_index)
+            for cand in handles:
+                if str(amdsmi.amdsmi_get_gpu_device_bdf(cand)).lower().startswith(want):
+                    h = cand
+                    break
+            else:
+                h = handles[device_index]
+        except Exception:
+            h = handles[min(device_index, len(handles) - 1)]
+        clk = amdsmi.AmdSmiClkType.GFX
+
+        def num(v):
+            return float(v) if isinstance(v, (int, float)) or (isinstance(v, str) and v.replace(".", "", 1).isdigit()) else None
+
+        def read():
+            pw = amdsmi.amdsmi_get_power_info(h)
+            w = num(pw.get("current_socket_power"))
+            if not w:
+                w = num(pw.get("average_socket_power"))
+            ck = amdsmi.amdsmi_get_clock_info(h, clk)
+            return num(ck.get("clk", ck.get("cur_clk"))), w
+        mhz, w = read()
+        if mhz is None and w is None:
+            raise RuntimeError("amdsmi returns no clock / power on this box")
+        try:
+            cap = amdsmi.amdsmi_get_power_cap_info(h)
+            c = num(cap.get("power_cap"))
+            self.cap_w = c / 1e6 if c and c > 1e5 else c     # uW in older bindings, W in newer ones
+        except Exception:
+            pass
+        self._read, self.source = read, "amdsmi (amdsmi_get_clock_info GFX, amdsmi_get_power_info socket power)"
+
+    def _init_sysfs(self, device_index):
+        import glob
+        want = self._bdf(device_index)
+        every = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in every if want in os.path.realpath(c).lower()]          # the device torch calls `device_index`
+        if not cards:
+            with_hwmon = [c for c in every if os.path.isdir(os.path.join(c, "hwmon"))]
+            cards = [with_hwmon[min(device_index, len(with_hwmon) - 1)]]
+        hw = sorted(glob.glob(os.path.join(cards[0], "hwmon", "hwmon*")))[0]
+        pfile = next(f for f in (os.path.join(hw, n) for n in ("power1_input", "power1_average")) if os.path.isfile(f))
+        ffile = os.path.join(hw, "freq1_input")
+
+        def read():
+            with open(pfile) as f:
+                w = float(f.read()) / 1e6
+            mhz = None
+            if os.path.isfile(ffile):
+                with open(ffile) as f:
+                    mhz = float(f.read()) / 1e6
+            return mhz, w
+        read()
+        capf = os.path.join(hw, "power1_cap")
+        if os.path.isfile(capf):
+            with open(capf) as f:
+                self.cap_w = float(f.read()) / 1e6
+        self._read, self.source = read, f"sysfs {hw} ({os.path.basename(pfile)}, freq1_input)"
+
+    def _loop(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append((time.perf_counter(),) + tuple(self._read()))
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self._read is not None:
+            import threading
+            self.samples, self._stop = [], threading.Event()
+            self._thread = threading.Thread(target=self._loop, name="fcp-telemetry", daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=2)
+            self._thread = None
+
+    def summary(self, t0=None, t1=None):
+        """Mean / min / max over the samples taken inside [t0, t1] (perf_counter; default: all)."""
+        rows = [r for r in self.samples if (t0 is None or r[0] >= t0) and (t1 is None or r[0] <= t1)]
+        mhz = [r[1] for r in rows if r[1]]
+        w = [r[2] for r in rows if r[2]]
+        st = lambda v: (round(sum(v) / len(v), 1), round(min(v), 1), round(max(v), 1)) if v else (None, None, None)
+        (cm, cl, ch), (pm, pl, ph) = st(mhz), st(w)
+        return {"source": self.source, "samples": len(rows), "period_ms": round(self.period * 1e3, 1),
+                "mean_sclk_mhz": cm, "min_sclk_mhz": cl, "max_sclk_mhz": ch,
+                "mean_power_w": pm, "min_power_w": pl, "max_power_w": ph, "power_cap_w": self.cap_w}
 
 
 class Pipeline:
@@ -226,9 +357,11 @@ class Pipeline4K(Pipeline):
                 f"{self.out_size}x{self.out_size}")
 
 
-def time_pipeline(p: Pipeline, steps, warmup, autotune=True, dist=None, live_events=False):
+def time_pipeline(p: Pipeline, steps, warmup, autotune=True, dist=None, live_events=False, telemetry=None):
     """Initialisation pass (lazy loads, tile tuning), `warmup` untimed steps, then exactly `steps` timed steps
-    bracketed by barrier + synchronize.  Returns (elapsed seconds, faces counted in the timed steps)."""
+    bracketed by barrier + synchronize.  Returns (elapsed seconds, faces counted in the timed steps).  ``telemetry``: a
+    ``Telemetry`` that samples clock / power while the timed steps run; its summary of exactly that window is left in
+    ``p.telemetry``."""
     from face_crop_plus_amd import engine as E
     E.Autotune.enabled = autotune
     p.step(True)
@@ -244,6 +377,8 @@ def time_pipeline(p: Pipeline, steps, warmup, autotune=True, dist=None, live_eve
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    if telemetry is not None:
+        telemetry.__enter__()
     t0 = time.perf_counter()
     for _ in range(steps):
         p.step(True)
@@ -251,7 +386,11 @@ def time_pipeline(p: Pipeline, steps, warmup, autotune=True, dist=None, live_eve
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, p.face_total.clone()
+    t1 = time.perf_counter()
+    if telemetry is not None:
+        telemetry.__exit__()
+        p.telemetry = telemetry.summary(t0, t1)
+    return t1 - t0, p.face_total.clone()
 
 
 def _pmc_traffic(key):
@@ -277,6 +416,7 @@ def conv_roofline(p: Pipeline, nsteps, live, timed_ms=None, traffic_key=None, ta
     engine sustained inside the timed region itself (the step also holds the non-conv kernels)."""
     from face_crop_plus_amd import engine as E
     timed_streams = p.det.streams
+    pass_sclk = None                    # mean engine clock of the per-launch passes (sampled when the launch table is written)
     if not live:
         saved, p.det.streams = p.det.streams, 1
         graphed, p.graphed = p.graphed, None          # per-launch events need the eager launches
@@ -287,20 +427,38 @@ def conv_roofline(p: Pipeline, nsteps, live, timed_ms=None, traffic_key=None, ta
         torch.cuda.synchronize()
         E.Autotune.enabled = tuned
         E.ConvStats.timing = []
+        tele = Telemetry(p.dev.index or 0, period_s=0.005) if table else None
+        if tele is not None:
+            tele.__enter__()
         for _ in range(nsteps):
             p.step(False)
         torch.cuda.synchronize()
+        if tele is not None:
+            tele.__exit__()
+            pass_sclk = tele.summary().get("mean_sclk_mhz")
         p.det.streams, p.graphed = saved, graphed
     timing, E.ConvStats.timing = E.ConvStats.timing, None
     if LAUNCH_TABLE and timed_ms is not None and table:
+        # Per launch: measured us beside two floors — algorithmic HBM bytes at the rate the streaming copy kernel reaches
+        # (6.3 TB/s) and EXECUTED matrix FLOP (3 MFMAs per product on the fp16x3 path) at the dense f16 peak scaled to the
+        # mean engine clock of these passes.  floor_max = perfect overlap of the two, floor_sum = none (at the socket power cap
+        # joules add: DESIGN.md section 6); us / floor_sum <= 1.15 is physics on this socket, above it a kernel problem.
+        # tools/launch_ledger.py adds W / MHz / joules per launch from steady loops of each launch alone.
         import csv
         per = len(timing) // nsteps
+        mult = 3 if p.precision == "f16x3" else 1
+        peak_at_clock = (F16_MFMA_PEAK_TFLOPS if mult == 3 else FP32_MFMA_PEAK_TFLOPS) * 1e12 * ((pass_sclk or 2400.0) / 2400.0)
         with open(LAUNCH_TABLE, "w", newline="") as f:
             wr = csv.writer(f)
-            wr.writerow(["launch", "us", "algorithmic_tflops", "algorithmic_gb_per_s"])
+            wr.writerow(["launch", "us", "algorithmic_tflops", "algorithmic_gb_per_s", "executed_gflop", "algorithmic_mb", "pass_mean_sclk_mhz",
+                         "floor_hbm_us", "floor_mfma_us", "floor_max_us", "floor_sum_us", "us_over_floor_max", "us_over_floor_sum"])
             for i in range(per):
                 us = sum(timing[i + s_ * per][0].elapsed_time(timing[i + s_ * per][1]) for s_ in range(nsteps)) / nsteps * 1e3
-                wr.writerow([timing[i][3], round(us, 1), round(timing[i][2] / us / 1e6, 1), round(timing[i][4] / us / 1e3, 1)])
+                f_hbm, f_mfma = timing[i][4] / 6.3e12 * 1e6, timing[i][2] * mult / peak_at_clock * 1e6
+                wr.writerow([timing[i][3], round(us, 1), round(timing[i][2] / us / 1e6, 1), round(timing[i][4] / us / 1e3, 1),
+                             round(timing[i][2] * mult / 1e9, 2), round(timing[i][4] / 1e6, 2), pass_sclk,
+                             round(f_hbm, 1), round(f_mfma, 1), round(max(f_hbm, f_mfma), 1), round(f_hbm + f_mfma, 1),
+                             round(us / max(f_hbm, f_mfma), 2), round(us / (f_hbm + f_mfma), 2)])
     conv_ms = sum(t[0].elapsed_time(t[1]) for t in timing) / nsteps
     conv_flops = sum(t[2] for t in timing) / nsteps
     launches = len(timing) // nsteps
@@ -425,7 +583,7 @@ def run_extra(dev, sds, args):
                 kw["strategy"] = args.strategy
             p = cls(dev, sds["retinaface"], out_size=args.out_size, streams=args.streams,
                     seed=4321, sd_enh=sds.get("rrdb"), sd_par=sds.get("bisenet"), **kw)
-            elapsed, faces = time_pipeline(p, steps, warmup, autotune=not args.no_autotune)
+            elapsed, faces = time_pipeline(p, steps, warmup, autotune=not args.no_autotune, telemetry=Telemetry(dev.index or 0))
             rec = {"workload": p.describe(), "note": note, "value": round(int(faces.item()) / elapsed, 2),
                    "unit": "faces/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
                    "dtype": p.precision}
@@ -436,6 +594,7 @@ def run_extra(dev, sds, args):
                 rec["frames_per_s"] = round(p.batch * steps / elapsed, 2)
             rec["roofline"] = conv_roofline(p, 1 if p.enh is not None else 2, live=False,
                                             timed_ms=elapsed / steps * 1e3, traffic_key=traffic_key)
+            attach_telemetry(rec["roofline"], getattr(p, "telemetry", None))
             if hbm:
                 rec["hbm_kernels"] = hbm_kernel_records(p)
             out[key] = rec
@@ -447,9 +606,13 @@ def run_extra(dev, sds, args):
 
     from face_crop_plus_amd import weights
     sds = dict(sds, rrdb=weights.generate_state_dict("rrdb"), bisenet=weights.generate_state_dict("bisenet"))
-    one("c3_detect_align_crop_1024", "the north-star metric at the north-star geometry: detect + align + crop (no parse, no "
-        "RRDB) on batch 32 @1024x1024 — the per-GPU rate that decides >= 10 k faces/s on 8 GPUs (needs >= 1250)", 10, 3,
-        full=False, batch=32, size=1024, precision="f16x3", enhance="none", traffic_key="c3det_pmc", hbm=True)
+    if (args.batch, args.size) != (64, 640):
+        one("c2_detect_align_crop_640", "BASELINE configs[1]: detect + align + crop on batch 64 @640x640 (the headline of rounds "
+            "1-5)", 20, 5, full=False, batch=64, size=640, precision="f16x3", enhance="none", traffic_key="f16x3_pmc_conv", hbm=True)
+    if (args.batch, args.size) != (32, 1024):
+        one("c3_detect_align_crop_1024", "the north-star metric at the north-star geometry: detect + align + crop (no parse, no "
+            "RRDB) on batch 32 @1024x1024 — the per-GPU rate that decides >= 10 k faces/s on 8 GPUs (needs >= 1250)", 20, 5,
+            full=False, batch=32, size=1024, precision="f16x3", enhance="none", traffic_key="c3det_pmc", hbm=True)
     one("c3_full_no_enhance", "BASELINE configs[2] without enhancement: detect + align + BiSeNet parse", 5, 2,
         full=True, batch=32, size=1024, precision="f16x3", enhance="none", traffic_key="c3_pmc")
     one("c3_full_enhance_all", "configs[2] with RRDB on EVERY image (worst case), batch reduced to 2: the enhancer "
@@ -476,9 +639,9 @@ def main():
                                                     # (what FCP_TUNE_TABLES=0 does; FCP_AUTOTUNE=0 alone keeps the tables)
     full = args.workload == "full"
     if args.batch is None:
-        args.batch = 32 if full else 64
+        args.batch = 32
     if args.size is None:
-        args.size = 1024 if full else 640
+        args.size = 1024
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)                        # never returns: one rank per GPU under torch.distributed.run
     rank = int(os.environ.get("RANK", "0"))
@@ -527,7 +690,9 @@ def main():
                  precision=args.precision, enhance=args.enhance if full else "none", streams=args.streams,
                  seed=1234 + rank, graph=args.graph, sd_enh=sds.get("rrdb"), sd_par=sds.get("bisenet"))
     live = rank == 0 and args.streams <= 1 and not args.graph
-    elapsed, faces = time_pipeline(p, args.steps, args.warmup, autotune=not args.no_autotune, dist=dist, live_events=live)
+    tele = Telemetry(local_rank) if rank == 0 else None
+    elapsed, faces = time_pipeline(p, args.steps, args.warmup, autotune=not args.no_autotune, dist=dist, live_events=live,
+                                   telemetry=tele)
     last_timed = p.last                            # outputs of the LAST TIMED step (the roofline passes below overwrite p.last)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -539,10 +704,15 @@ def main():
     roofline = cpu_baseline = extra = parity_check = None
     hbm_kernels = None
     if rank == 0:
-        std = not full and args.batch == 64 and args.size == 640
-        key = ("f16x3_pmc_conv" if args.precision == "f16x3" else "f32_pmc_conv") if std else None
+        # committed PMC measurement of the same workload (profiles/): north-star geometry or configs[1]
+        key = None
+        if not full and (args.batch, args.size) == (32, 1024) and args.precision == "f16x3":
+            key = "c3det_pmc"
+        elif not full and (args.batch, args.size) == (64, 640):
+            key = "f16x3_pmc_conv" if args.precision == "f16x3" else "f32_pmc_conv"
         roofline = conv_roofline(p, args.steps if live else args.roofline_steps, live,
                                  timed_ms=elapsed / args.steps * 1e3, traffic_key=key, table=True)
+        attach_telemetry(roofline, getattr(p, "telemetry", None))
         if not args.graph:
             try:
                 hbm_kernels = hbm_kernel_records(p)
@@ -587,6 +757,21 @@ def main():
         dist.destroy_process_group()
 
 
+def attach_telemetry(roofline, tele):
+    """Clock / power of the timed region into a roofline record: the two means as scalars (what a reader compares between
+    boxes / rounds), the whole summary beside them, and the MFMA peak the mean clock allows (peak x sclk / 2400 MHz) with the
+    fraction of THAT the timed region reached."""
+    if roofline is None or not tele:
+        return roofline
+    roofline["mean_sclk_mhz"], roofline["mean_power_w"] = tele.get("mean_sclk_mhz"), tele.get("mean_power_w")
+    roofline["telemetry"] = dict(tele, window="the timed steps (between the two synchronisations)")
+    if tele.get("mean_sclk_mhz") and roofline.get("achieved_timed"):
+        at_clock = roofline["peak"] * tele["mean_sclk_mhz"] / 2400.0
+        roofline["peak_at_mean_sclk"] = round(at_clock, 1)
+        roofline["frac_timed_at_mean_sclk"] = round(roofline["achieved_timed"] / at_clock, 4)
+    return roofline
+
+
 def finalize_line(line, extra):
     """Attach the `extra` records, lift the north-star record (batch 32 @1024^2, detect + align + crop: the per-GPU rate that
     decides >= 10 k faces/s on 8 GPUs) into `config` / `roofline` — nested, and as scalars for consumers that flatten nested
@@ -595,6 +780,16 @@ def finalize_line(line, extra):
     still sees the workload, the roofline and the north-star record."""
     if extra is not None:
         line["extra"] = extra
+        c1 = extra.get("c2_detect_align_crop_640", {})
+        if "value" in c1:                                   # BASELINE configs[1] beside a north-star-geometry headline
+            for where in (line["roofline"], line["config"]):
+                where["configs1_value"] = c1["value"]
+                where["configs1_unit"] = "faces/s, batch 64 @640x640, detect+align+crop, 1 GPU (BASELINE configs[1])"
+                where["configs1_ms_per_step"], where["configs1_steps"] = c1["ms_per_step"], c1["steps"]
+                where["configs1_frac"] = c1["roofline"]["frac"]
+                where["configs1_frac_timed"] = c1["roofline"].get("frac_timed")
+                where["configs1_mean_sclk_mhz"] = c1["roofline"].get("mean_sclk_mhz")
+                where["configs1_mean_power_w"] = c1["roofline"].get("mean_power_w")
         ns = extra.get("c3_detect_align_crop_1024", {})
         if "value" in ns:
             line["config"]["north_star_geometry"] = {

@@ -398,6 +398,18 @@ class ConvStats:
     flops = 0
     launches = 0
     timing = None  # list of (start_event, end_event, flops, label, algorithmic bytes) when per-launch timing is on
+    # list of (label, flops, algorithmic bytes, relaunch) when capture is on: ``relaunch()`` enqueues the very same launch again
+    # (same descriptor, same tensors — kept alive by the closure) on the current stream.  tools/launch_ledger.py loops each
+    # launch of a step on its own while clock / power are sampled (ctypes boundary only: the registered ops build no descriptor).
+    replay = None
+
+    @classmethod
+    def note(cls, timing, e0, e1, flops, label, byts, relaunch=None):
+        if timing is not None:
+            e1.record()
+            timing.append((e0, e1, flops, label, byts))
+        if cls.replay is not None and relaunch is not None:
+            cls.replay.append((label, flops, byts, relaunch))
 
     @classmethod
     def reset(cls):
@@ -624,14 +636,15 @@ def conv(pc: PackedConv, x: Act, out: Act | None = None, *, act_slope: float = 1
                             0 if x2 is None else x2.c, int(x2_stride), int(d.flags), int(d.cu_budget), int(band[0]), int(band[1]))
     else:
         N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32")
-    if timing is not None:
-        e1.record()
+    if timing is not None or ConvStats.replay is not None:
         byts = 4 * (m * (pc.cout + (pc.cout if res1 is not None else 0) + (pc.cout if res2 is not None else 0))
                     + x.n * in_h * in_w * x.c // (4 if in_up2 else 1) + (m * x2.c if x2 is not None else 0)
                     + pc.cout * pc.cin * pc.kh * pc.kw)
-        timing.append((e0, e1, pc.flops_per_pixel * m,
+        keep = (pc, x, x2, res1, res2, out)
+        ConvStats.note(timing, e0 if timing is not None else None, e1 if timing is not None else None, pc.flops_per_pixel * m,
                        f"conv {pc.kh}x{pc.kw} s{pc.stride} {pc.cin}->{pc.cout} @{oh}x{ow} tile {d.tile_m}x{d.tile_n}"
-                       f"{' bal' if d.flags & N.CONV_BALANCE_TAIL else ''}{' +res' if res1 is not None else ''}", byts))
+                       f"{' bal' if d.flags & N.CONV_BALANCE_TAIL else ''}{' +res' if res1 is not None else ''}", byts,
+                       lambda d=d, keep=keep: N.check(N.lib().fcp_conv2d_nhwc_f32(C.byref(d), N.stream_ptr()), "fcp_conv2d_nhwc_f32"))
     if ConvStats.enabled:
         ConvStats.flops += pc.flops_per_pixel * m
         ConvStats.launches += 1
@@ -730,6 +743,7 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
     if tile_m is None:
         tile_m = 16 if (pc2 is not None and CHAIN_PATCH and CHAIN_TILE_M == 0) else (CHAIN_TILE_M if (pc2 is not None or CHAIN_TILE_M not in (16, 32)) else 0)
     flags = N.CHAIN_OUT_EVEN_ONLY if (out_even_only and tile_m in (16, 32) and CHAIN_SPARSE_OUT and RangeMonitor.active is None) else 0
+    d = None
     if T.ENABLED and out is None and t1n is None:
         # FCP_BOUNDARY=torch: the registered custom op allocates and returns both tensors
         o, t = T.load().bottleneck_chain(t1.buf, t1.c0, None if res is None else res.buf, 0 if res is None else res.c0,
@@ -755,13 +769,17 @@ def bottleneck_chain(pc2: PackedConv | None, pc3: PackedConv, pc1n: PackedConv, 
         if t1b is not None:
             d.t1b, d.cb, d.t1b_ld, d.t1b_h, d.t1b_w, d.t1b_stride = t1b.ptr(), cb, t1b.ld, t1b.h, t1b.w, t1b_stride
         N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
-    if timing is not None:
-        e1.record()
+    if timing is not None or ConvStats.replay is not None:
         c, nout, cn = pc3.cin, pc3.cout, pc1n.cout
         byts = 4 * (m * (c + (nout if not flags else nout // 4) + (nout if res is not None else 0) + cn) + (0 if pc2 is None else 9 * c * c)
                     + c * nout + nout * cn)
-        timing.append((e0, e1, flops, f"chain {'3x3 ' if pc2 is not None else ''}{c}->{nout}->{cn} @{t1.h}x{t1.w}"
-                       f"{' +res' if res is not None else ''}{' out@even' if flags else ''}{' two-source' if t1b is not None else ''}", byts))
+        relaunch = None
+        if d is not None:
+            keep = (pc2, pc3, pc1n, t1, res, out, t1n, t1b)
+            relaunch = lambda d=d, keep=keep: N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
+        ConvStats.note(timing, e0 if timing is not None else None, e1 if timing is not None else None, flops,
+                       f"chain {'3x3 ' if pc2 is not None else ''}{c}->{nout}->{cn} @{t1.h}x{t1.w}"
+                       f"{' +res' if res is not None else ''}{' out@even' if flags else ''}{' two-source' if t1b is not None else ''}", byts, relaunch)
     if ConvStats.enabled:
         ConvStats.flops += flops
         ConvStats.launches += 1
@@ -796,10 +814,13 @@ def _expand_conv3(pc3: PackedConv, t1: Act, res: Act, out: Act | None):
         d.t1_ld, d.res_ld, d.out_ld = t1.ld, res.ld, out.ld
         N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
     flops = pc3.flops_per_pixel * m
-    if timing is not None:
-        e1.record()
-        timing.append((e0, e1, flops, f"expand {pc3.cin}->{pc3.cout} @{t1.h}x{t1.w} +res",
-                       4 * (m * (pc3.cin + 2 * pc3.cout) + pc3.cin * pc3.cout)))
+    if timing is not None or ConvStats.replay is not None:
+        relaunch = None
+        if not via_op:
+            keep = (pc3, t1, res, out)
+            relaunch = lambda d=d, keep=keep: N.check(N.lib().fcp_bottleneck_chain_f16x3(C.byref(d), N.stream_ptr()), "fcp_bottleneck_chain_f16x3")
+        ConvStats.note(timing, e0 if timing is not None else None, e1 if timing is not None else None, flops,
+                       f"expand {pc3.cin}->{pc3.cout} @{t1.h}x{t1.w} +res", 4 * (m * (pc3.cin + 2 * pc3.cout) + pc3.cin * pc3.cout), relaunch)
     if ConvStats.enabled:
         ConvStats.flops += flops
         ConvStats.launches += 1
@@ -900,10 +921,11 @@ def stem_relu_pool_u8(ps: PackedStem, images_u8: torch.Tensor, out: Act | None =
         N.check(N.lib().fcp_stem7x7s2_relu_pool_u8(N.ptr(images_u8), n, h, w, mean, N.ptr(ps.wfrag), N.ptr(ps.bias),
                                                    N.ptr(ps.wscale), out.ptr(), out.ld, out.fmt, N.stream_ptr()),
                 "fcp_stem7x7s2_relu_pool_u8")
-    if timing is not None:
-        e1.record()
+    if timing is not None or ConvStats.replay is not None:
         byts = n * h * w * 3 + 4 * n * hp * wp * 64 * (2 if conv1 is not None else 1)
-        timing.append((e0, e1, flops, f"stem 7x7 s2 + pool{' + conv1' if conv1 is not None else ''} @{hp}x{wp}", byts))
+        ConvStats.note(timing, e0 if timing is not None else None, e1 if timing is not None else None, flops,
+                       f"stem 7x7 s2 + pool{' + conv1' if conv1 is not None else ''} @{hp}x{wp}", byts,
+                       lambda: stem_relu_pool_u8(ps, images_u8, out, mean_rgb, out_fmt, conv1, t1))   # (replayed with capture switched off)
     if ConvStats.enabled:
         ConvStats.flops += flops
         ConvStats.launches += 1
@@ -932,8 +954,7 @@ def stem_relu_pool_f32(ps: PackedStem, x4: Act, out: Act | None = None, out_fmt:
                                                 out.ptr(), out.ld, out.fmt, N.stream_ptr()), "fcp_stem7x7s2_relu_pool_f32")
     flops = ps.flops_per_pixel * n * hs * ws
     if timing is not None:
-        e1.record()
-        timing.append((e0, e1, flops, f"stem(f32) 7x7 s2 + pool @{hp}x{wp}", n * h * w * 16 + 4 * n * hp * wp * 64))
+        ConvStats.note(timing, e0, e1, flops, f"stem(f32) 7x7 s2 + pool @{hp}x{wp}", n * h * w * 16 + 4 * n * hp * wp * 64)
     if ConvStats.enabled:
         ConvStats.flops += flops
         ConvStats.launches += 1

@@ -134,5 +134,48 @@ def test_bench_line_shape_for_consumers_that_flatten_or_keep_the_tail():
         assert out[where]["north_star_geometry_value"] == 1380.0 and out[where]["north_star_geometry_frac"] == 0.1326
         assert out[where]["north_star_geometry_ms_per_step"] == 23.2 and out[where]["north_star_geometry_steps"] == 10
     assert text.rindex('"north_star_geometry_value"') > text.rindex('"hbm_kernels"')      # visible in the tail
+    # round 6: the north-star geometry IS the headline; BASELINE configs[1] comes from `extra` and is lifted as configs1_* scalars
+    line6 = {"metric": "faces/sec end-to-end (detect+align+crop)", "value": 1400.0, "config": {"workload": "w"}, "roofline": {"frac": 0.13},
+             "cpu_baseline": {"value": 1.0}}
+    extra6 = {"c2_detect_align_crop_640": {"workload": "c", "value": 3500.0, "unit": "faces/s", "ms_per_step": 18.2, "steps": 20, "warmup": 5,
+                                           "roofline": {"frac": 0.112, "frac_timed": 0.122, "mean_sclk_mhz": 2100.0, "mean_power_w": 1390.0}}}
+    out6 = bench.finalize_line(line6, extra6)
+    for where in ("roofline", "config"):
+        assert out6[where]["configs1_value"] == 3500.0 and out6[where]["configs1_frac_timed"] == 0.122
+        assert out6[where]["configs1_mean_sclk_mhz"] == 2100.0 and "north_star_geometry_value" not in out6[where]
     plain = bench.finalize_line({"metric": "m", "value": 1.0, "config": {}, "roofline": {}}, None)   # --no-extra: nothing to lift
     assert list(plain) == ["metric", "value", "config", "roofline"]
+
+
+def test_telemetry_samples_a_window_and_lands_in_the_roofline_record():
+    """Clock / power sampling beside the timed region: a reader thread, mean / min / max over exactly the timed window, the two
+    means as scalars of the roofline record and the MFMA peak re-priced at the mean clock; no source -> no fields, no failure."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    t = bench.Telemetry.__new__(bench.Telemetry)              # no GPU here: feed the reader by hand
+    import threading
+    t.period, t.samples, t._stop, t._thread, t.cap_w = 0.002, [], threading.Event(), None, 1400.0
+    seq = iter([(2400.0, 300.0)] * 3 + [(2000.0 + 10 * i, 1390.0 + (i % 3)) for i in range(10000)])
+    t._read, t.source = (lambda: next(seq)), "fake"
+    with t:
+        time.sleep(0.03)
+        t0 = time.perf_counter()
+        time.sleep(0.08)
+        t1 = time.perf_counter()
+        time.sleep(0.02)
+    s = t.summary(t0, t1)
+    assert 10 <= s["samples"] < len(t.samples) and s["source"] == "fake" and s["power_cap_w"] == 1400.0
+    assert s["min_sclk_mhz"] > 2000.0 and s["max_sclk_mhz"] < 2400.0 + 10 * len(t.samples)      # the idle head is outside the window
+    assert s["min_sclk_mhz"] <= s["mean_sclk_mhz"] <= s["max_sclk_mhz"] and 1390.0 <= s["mean_power_w"] <= 1392.0
+    roof = bench.attach_telemetry({"peak": 2500.0, "achieved_timed": 300.0, "frac_timed": 0.12}, dict(s, mean_sclk_mhz=2000.0))
+    assert roof["mean_sclk_mhz"] == 2000.0 and roof["mean_power_w"] == s["mean_power_w"]
+    assert roof["peak_at_mean_sclk"] == round(2500.0 * 2000 / 2400, 1) and roof["frac_timed_at_mean_sclk"] == round(300.0 / (2500.0 * 2000 / 2400), 4)
+    assert bench.attach_telemetry({"peak": 1.0}, None) == {"peak": 1.0}
+    dead = bench.Telemetry.__new__(bench.Telemetry)
+    dead.period, dead.samples, dead._stop, dead._thread, dead._read, dead.source, dead.cap_w = 0.01, [], threading.Event(), None, None, None, None
+    with dead:
+        pass
+    assert dead.summary()["mean_sclk_mhz"] is None and dead.summary()["samples"] == 0
+    real = bench.Telemetry(0)                                  # this container has no GPU: must degrade, not raise
+    assert real.source is None or isinstance(real.source, str)
