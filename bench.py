@@ -83,6 +83,7 @@ def parse():
     ap.add_argument("--launch-table", default=None, metavar="CSV",
                     help="write the per-launch table of the roofline passes (label, us, TFLOP/s, algorithmic GB/s) to this file")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    ap.add_argument("--no-telemetry", action="store_true", help="do not sample clock / power beside the timed regions")
     return ap.parse_args()
 
 
@@ -93,10 +94,14 @@ class Telemetry:
     (power1_input | power1_average in uW, freq1_input in Hz).  Nothing here touches the data path; every failure degrades to
     ``{"source": None}``."""
 
+    disabled = False                     # --no-telemetry
+
     def __init__(self, device_index=0, period_s=0.01):
         import threading
         self.period, self.samples, self._stop, self._thread = period_s, [], threading.Event(), None
         self.source, self._read, self.cap_w = None, None, None
+        if Telemetry.disabled:
+            return
         try:
             self._init_amdsmi(device_index)
         except Exception:
@@ -393,16 +398,29 @@ def time_pipeline(p: Pipeline, steps, warmup, autotune=True, dist=None, live_eve
     return t1 - t0, p.face_total.clone()
 
 
-def _pmc_traffic(key):
+def _pmc_traffic(key, launches=None):
     """Committed PMC measurement (HBM bytes per conv launch) of workload `key`, newest round first: counters cannot be
-    read from inside the process, so `traffic` is the rocprofv3 --pmc measurement of the same command."""
+    read from inside the process, so `traffic` is the rocprofv3 --pmc measurement of the same command.  A file recorded at
+    another ABI version than the library's, or for a step with another number of conv launches than this run's, is a
+    measurement of a different build: it is named, with the reason, and NOT quoted (traffic = None).
+    Returns (bytes per launch | None, "profiles/<file>" | None, stale reason | None)."""
     pdir = os.path.join(ROOT, "profiles")
     prof = sorted(f for f in os.listdir(pdir) if f.endswith(f"_{key}.json")) if os.path.isdir(pdir) else []
     if not prof:
-        return None, None
+        return None, None, None
     with open(os.path.join(pdir, prof[-1])) as f:
-        return round(json.load(f)["hbm_bytes_per_launch"]), "profiles/" + prof[-1]
+        rec = json.load(f)
+    from face_crop_plus_amd._native import ABI_VERSION
+    stale = None
+    if rec.get("abi_version") != ABI_VERSION:
+        stale = f"recorded at ABI {rec.get('abi_version', 'unknown')}, the library is ABI {ABI_VERSION}"
+    elif launches is not None and rec.get("launches_per_step") != launches:
+        stale = f"recorded for {rec.get('launches_per_step')} conv launches per step, this step has {launches}"
+    return (None if stale else round(rec["hbm_bytes_per_launch"])), "profiles/" + prof[-1], stale
 
+
+# the workloads whose `roofline.traffic` bench.py quotes from profiles/ (tools/profile_round.sh regenerates all of them in one call)
+TRAFFIC_KEYS = ("c3det_pmc", "f16x3_pmc_conv", "c3_pmc", "rrdb_pmc", "f32_pmc_conv")
 
 AUTOTUNE_ROOFLINE = True            # --no-autotune / FCP_AUTOTUNE=0 hold for the roofline passes too (recorded in the entry)
 LAUNCH_TABLE = None                 # --launch-table: CSV path for the per-launch table of the headline workload's roofline passes
@@ -465,7 +483,7 @@ def conv_roofline(p: Pipeline, nsteps, live, timed_ms=None, traffic_key=None, ta
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
     split = p.precision == "f16x3"
     peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-    traffic, traffic_src = _pmc_traffic(traffic_key) if traffic_key else (None, None)
+    traffic, traffic_src, traffic_stale = _pmc_traffic(traffic_key, launches) if traffic_key else (None, None, None)
     rec = {"bound": "mfma",
            "kernel": ("conv_igemm_f16x3 family (3x v_mfma_f32_32x32x16_f16 per product: x = hi + lo split)" if split
                       else "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)"),
@@ -479,6 +497,7 @@ def conv_roofline(p: Pipeline, nsteps, live, timed_ms=None, traffic_key=None, ta
            # PMC counters cannot be read from inside the process: `traffic` is the committed rocprofv3 --pmc
            # measurement of this same command, not a value measured in this run
            "traffic_static": traffic is not None,
+           "traffic_stale": traffic_stale,        # why the newest committed measurement is not quoted (None: it is, or there is none)
            "measured": ("HIP events around every conv launch of the timed steps" if live else
                         f"HIP events around every conv launch of {nsteps} single-stream passes over the batch right "
                         f"after the timed region"),
@@ -633,6 +652,7 @@ def main():
     global LAUNCH_TABLE, AUTOTUNE_ROOFLINE
     LAUNCH_TABLE = args.launch_table
     AUTOTUNE_ROOFLINE = not args.no_autotune and os.environ.get("FCP_AUTOTUNE", "1") != "0"
+    Telemetry.disabled = args.no_telemetry
     if args.no_autotune:
         from face_crop_plus_amd import engine as _E
         _E.Autotune.use_tables = False              # heuristic tiles: neither tuning launches nor the shipped / user tables

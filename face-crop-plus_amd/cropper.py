@@ -407,8 +407,9 @@ class Cropper:
                 # one HIP stream per GPU worker: the batches of different workers overlap on the device (the tail of
                 # one kernel with the head of another; measured +4 % at two streams) instead of queueing on stream 0
                 if not hasattr(tls, "stream"):
+                    from . import engine as E
                     with torch.cuda.device(self.device):
-                        tls.stream = torch.cuda.Stream()
+                        tls.stream = E.thread_main_stream(self.device)           # the same streams again in every run
                         tls.stream.wait_stream(torch.cuda.default_stream())      # filters were uploaded there
                 with torch.cuda.device(self.device), torch.cuda.stream(tls.stream):
                     self._process_images(images, names, output_dir, pinned)

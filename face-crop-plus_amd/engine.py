@@ -213,6 +213,66 @@ def device_props(dev=None):
     return got
 
 
+class _StreamClaim:
+    """Held in a host thread's thread-local storage: gives the thread's slot back when the thread ends."""
+
+    def __init__(self, dev_index, slot):
+        self.dev_index, self.slot = dev_index, slot
+
+    def __del__(self):
+        try:
+            with _stream_lock:
+                _stream_free.setdefault(self.dev_index, set()).add(self.slot)
+        except Exception:                                    # interpreter shutdown
+            pass
+
+
+_stream_lock = threading.Lock()
+_stream_sets: dict = {}          # device index -> [slot -> {"main": Stream | None, "side": {k: [k Streams]}}]
+_stream_free: dict = {}          # device index -> slots no living thread holds
+_stream_tls = threading.local()
+
+
+def thread_streams(dev) -> dict:
+    """The calling host thread's persistent set of HIP streams on ``dev``: ``{"main": ..., "side": {k: [...]}}`` (both filled
+    lazily by ``thread_main_stream`` / ``thread_side_streams``).  Sets live in process-wide SLOTS: a thread claims the lowest
+    free slot at its first call and gives it back when it ends, so the GPU worker threads of successive ``process_dir``
+    runs — and every detector object a thread runs — get the SAME streams again instead of fresh ones.  Why that matters
+    (profiles/r06_probes.md section 2): HIP multiplexes streams onto GPU_MAX_HW_QUEUES (4) hardware queues, and the side streams of a
+    second, freshly created pair were measured sharing one queue: the detector's two half-batches then run one after the other
+    (17.9 -> 20.3 ms per batch-64 step) — every `extra` record of bench.py paid that until round 6."""
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    claims = _stream_tls.__dict__.setdefault("claims", {})
+    claim = claims.get(idx)
+    with _stream_lock:
+        sets = _stream_sets.setdefault(idx, [])
+        if claim is None:
+            free = _stream_free.setdefault(idx, set())
+            slot = min(free) if free else len(sets)
+            free.discard(slot)
+            if slot == len(sets):
+                sets.append({"main": None, "side": {}})
+            claim = claims[idx] = _StreamClaim(idx, slot)
+        return sets[claim.slot]
+
+
+def thread_side_streams(dev, k: int):
+    """k side streams of the calling thread (the detector's half-batches)."""
+    st = thread_streams(dev)
+    if k not in st["side"]:
+        st["side"][k] = [torch.cuda.Stream(device=dev) for _ in range(k)]
+    return st["side"][k]
+
+
+def thread_main_stream(dev):
+    """The stream a GPU worker thread of ``process_dir`` runs its batches on."""
+    st = thread_streams(dev)
+    if st["main"] is None:
+        st["main"] = torch.cuda.Stream(device=dev)
+    return st["main"]
+
+
 BIG_TILES = os.environ.get("FCP_BIG_TILES", "1") != "0"   # offer the 256-row kernel to the autotuner
 BALANCE_TAIL = os.environ.get("FCP_BALANCE_TAIL", "1") != "0"   # and its balanced M-tile schedule (FCP_CONV_BALANCE_TAIL)
 

@@ -269,12 +269,9 @@ class RetinaFace:
         return heads
 
     def _side_streams(self, dev, k):
-        """k HIP streams of the calling host thread (process_dir's GPU workers each get their own set)."""
-        have = self._tls.__dict__.setdefault("streams", {})
-        key = (dev.index, k)
-        if key not in have:
-            have[key] = [torch.cuda.Stream(device=dev) for _ in range(k)]
-        return have[key]
+        """k HIP streams of the calling host thread (process_dir's GPU workers each get their own set), shared by every
+        detector the thread runs and by the threads of later runs: ``engine.thread_side_streams``."""
+        return E.thread_side_streams(dev, k)
 
     def _forward_heads_split(self, images_u8: torch.Tensor):
         """``forward_heads`` of a uint8 batch, its ``self.streams`` contiguous sub-batches enqueued on side streams

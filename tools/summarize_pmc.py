@@ -37,8 +37,12 @@ stem_expected_kib = (CAL_N * (CAL_SIDE // 4) ** 2 * 64 * 4 if fused else CAL_N *
 read_corr = 2.0
 mfma_busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in s)
 gui = sum(v["GRBM_GUI_ACTIVE"] for v in s)               # summed over the 8 XCDs
+import os, re
+_hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fcp_hip.h")).read()
 out = {
     "command": f"{WHAT}, last step's {LAUNCHES} conv launches",
+    # what bench.py checks before it quotes this file as `roofline.traffic` (a measurement of another build is not evidence)
+    "abi_version": int(re.search(r"#define FCP_ABI_VERSION (\d+)", _hdr).group(1)), "launches_per_step": LAUNCHES,
     "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
     "fetch_calibration": {"launch": f[cal]["name"][:60], "reported_kib": f[cal]["FETCH_SIZE"],
                           "expected_kib": stem_expected_kib, "ratio": f[cal]["FETCH_SIZE"] / stem_expected_kib,
