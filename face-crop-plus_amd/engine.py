@@ -257,11 +257,64 @@ def thread_streams(dev) -> dict:
         return sets[claim.slot]
 
 
+STREAM_PROBE = os.environ.get("FCP_STREAM_PROBE", "1") != "0"
+_stream_rejects: list = []       # streams that shared a queue with a chosen one: kept alive (their queue assignment stands)
+
+
+def _streams_overlap(a, b, cycles: int = 1_500_000) -> bool:
+    """Whether kernels on streams ``a`` and ``b`` run concurrently: a one-workgroup spin kernel (``torch.cuda._sleep``) on each;
+    two that share a hardware queue take twice as long as one (tools/probe_hw_queues.py: 1.0 x against 2.0 x, nothing between)."""
+    import time
+
+    def timed(streams):
+        for s_ in streams:
+            s_.synchronize()
+        t = time.perf_counter()
+        for s_ in streams:
+            with torch.cuda.stream(s_):
+                torch.cuda._sleep(cycles)
+        for s_ in streams:
+            s_.synchronize()
+        return time.perf_counter() - t
+    timed([a])                                               # first use: the runtime assigns the stream's hardware queue here
+    timed([b])
+    one = min(timed([a]), timed([b]))
+    return min(timed([a, b]), timed([a, b])) < 1.5 * one
+
+
+def _new_stream_beside(dev, others, tries: int = 6):
+    """A new stream whose kernels overlap with those of every stream in ``others``.  HIP assigns a stream to one of
+    GPU_MAX_HW_QUEUES (4) hardware queues at its first use — the least loaded one, so the 3rd and 4th streams of a process were
+    measured on ONE queue while the 1st / 2nd and 5th / 6th were on two (tools/probe_hw_queues.py, profiles/r06_probes.md section
+    2) — and two streams on one queue run their kernels one after the other.  Candidates that alias a chosen stream are set
+    aside (alive, so the next candidate lands elsewhere); after ``tries`` candidates the last one is taken as it is (more
+    streams than queues: some sharing is unavoidable, and only costs overlap)."""
+    with torch.cuda.device(dev):
+        cand = torch.cuda.Stream(device=dev)
+        if not STREAM_PROBE or not others or not hasattr(torch.cuda, "_sleep") or torch.cuda.is_current_stream_capturing():
+            return cand
+        for _ in range(tries):
+            try:
+                if all(_streams_overlap(o, cand) for o in others):
+                    return cand
+            except Exception:                                # a probe must never break the data path
+                return cand
+            _stream_rejects.append(cand)
+            cand = torch.cuda.Stream(device=dev)
+        return cand
+
+
 def thread_side_streams(dev, k: int):
-    """k side streams of the calling thread (the detector's half-batches)."""
+    """k side streams of the calling thread (the detector's sub-batches), on hardware queues of their own: distinct from each
+    other and from the thread's main stream if it has one."""
     st = thread_streams(dev)
     if k not in st["side"]:
-        st["side"][k] = [torch.cuda.Stream(device=dev) for _ in range(k)]
+        with _stream_lock:                                   # one prober at a time
+            chosen = [st["main"]] if st["main"] is not None else []
+            side = []
+            for _ in range(k):
+                side.append(_new_stream_beside(dev, chosen + side))
+        st["side"][k] = side
     return st["side"][k]
 
 
@@ -269,7 +322,8 @@ def thread_main_stream(dev):
     """The stream a GPU worker thread of ``process_dir`` runs its batches on."""
     st = thread_streams(dev)
     if st["main"] is None:
-        st["main"] = torch.cuda.Stream(device=dev)
+        with _stream_lock:
+            st["main"] = _new_stream_beside(dev, [x for v in st["side"].values() for x in v])
     return st["main"]
 
 

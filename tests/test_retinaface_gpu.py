@@ -175,3 +175,26 @@ def test_body_matches_transformers_resnet(sd, device):
             err = float(np.abs(got - ref).max()) / float(np.abs(ref).max())
             print(f"{precision} stage {k + 1}: relative error vs transformers {z['transformers_version']} ResNetModel {err:.2e}")
             assert err < tol, (precision, k, err)
+
+
+def test_a_threads_streams_sit_on_hardware_queues_of_their_own(device):
+    """HIP multiplexes streams onto 4 hardware queues, assigned at first use; the 3rd and 4th streams of a process were measured on
+    ONE queue (tools/probe_hw_queues.py), which serialised the two half-batches of every detector but the first (bench.py's
+    `extra` records ran 4-10 % slow until round 6).  ``engine.thread_*_streams`` probes: the side streams of this thread, and the
+    main + side streams of a second GPU worker thread, overlap pairwise."""
+    import threading
+    from face_crop_plus_amd import engine as E
+    a, b = E.thread_side_streams(device, 2)
+    assert E.thread_side_streams(device, 2)[0] is a
+    assert E._streams_overlap(a, b)
+    out = {}
+
+    def worker():
+        with torch.cuda.device(device):
+            m = E.thread_main_stream(device)
+            s0, s1 = E.thread_side_streams(device, 2)
+            out["ok"] = E._streams_overlap(s0, s1) and E._streams_overlap(m, s0) and E._streams_overlap(m, s1)
+            out["own"] = s0 is not a and s1 is not b
+    t = threading.Thread(target=worker)
+    t.start(); t.join()
+    assert out == {"ok": True, "own": True}
