@@ -304,26 +304,33 @@ def _new_stream_beside(dev, others, tries: int = 6):
         return cand
 
 
-def thread_side_streams(dev, k: int):
-    """k side streams of the calling thread (the detector's sub-batches), on hardware queues of their own: distinct from each
-    other and from the thread's main stream if it has one."""
+def thread_side_streams(dev, k: int, with_main: bool = False):
+    """k streams for the detector's k sub-batches (the heavy streams) of the calling thread, on hardware queues of their own.
+    ``with_main``: the thread's main stream is the first of the k (a GPU worker thread of ``process_dir`` that already runs on
+    its main stream: one sub-batch stays there, k - 1 side streams are added).  Measured with two GPU workers
+    (tools/bench_process_dir.py with FCP_STREAM_MATRIX=1, profiles/r06_probes.md section 2): when a worker's main stream
+    shared a queue with the OTHER worker's heavy stream — its decode / NMS / warp launches then queue behind the other
+    worker's convolutions — process_dir ran at 2.3-2.5 k images/s; with every main stream on the queue of its own sub-batch
+    3.0-3.3 k.  Only the thread's own streams are kept apart from each other; other threads' streams may share their queues."""
     st = thread_streams(dev)
-    if k not in st["side"]:
+    key = (k, bool(with_main))
+    if key not in st["side"]:
+        base = [thread_main_stream(dev)] if with_main else []
         with _stream_lock:                                   # one prober at a time
-            chosen = [st["main"]] if st["main"] is not None else []
-            side = []
-            for _ in range(k):
-                side.append(_new_stream_beside(dev, chosen + side))
-        st["side"][k] = side
-    return st["side"][k]
+            side = list(base)
+            while len(side) < k:
+                side.append(_new_stream_beside(dev, side))
+        st["side"][key] = side
+    return st["side"][key]
 
 
 def thread_main_stream(dev):
-    """The stream a GPU worker thread of ``process_dir`` runs its batches on."""
+    """The stream a GPU worker thread of ``process_dir`` runs its batches on (light work — fork / join of the side streams,
+    post-processing, align: it may share a queue with anything)."""
     st = thread_streams(dev)
     if st["main"] is None:
-        with _stream_lock:
-            st["main"] = _new_stream_beside(dev, [x for v in st["side"].values() for x in v])
+        with torch.cuda.device(dev):
+            st["main"] = torch.cuda.Stream(device=dev)
     return st["main"]
 
 

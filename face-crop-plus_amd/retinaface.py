@@ -270,8 +270,10 @@ class RetinaFace:
 
     def _side_streams(self, dev, k):
         """k HIP streams of the calling host thread (process_dir's GPU workers each get their own set), shared by every
-        detector the thread runs and by the threads of later runs: ``engine.thread_side_streams``."""
-        return E.thread_side_streams(dev, k)
+        detector the thread runs and by the threads of later runs: ``engine.thread_side_streams``.  A thread that is already
+        running on its own main stream (a GPU worker of process_dir) keeps one sub-batch there."""
+        main = E.thread_streams(dev)["main"]
+        return E.thread_side_streams(dev, k, with_main=main is not None and torch.cuda.current_stream(dev) == main)
 
     def _forward_heads_split(self, images_u8: torch.Tensor):
         """``forward_heads`` of a uint8 batch, its ``self.streams`` contiguous sub-batches enqueued on side streams
@@ -289,7 +291,8 @@ class RetinaFace:
         cus = E.device_props(dev).multi_processor_count // k if self.split_cu_budget else 0
         for st, a, b in zip(side, bounds[:-1], bounds[1:]):
             tuned = len(E.Autotune.cache)
-            st.wait_stream(cur)
+            if st != cur:
+                st.wait_stream(cur)
             with torch.cuda.stream(st), E.cu_budget(cus):
                 self.forward_heads(None, images_u8[a:b], [E.Act(hd.buf[a:b]) for hd in heads])
             if len(E.Autotune.cache) != tuned:
@@ -297,7 +300,8 @@ class RetinaFace:
                 # events, so let it finish alone before the next sub-batch, with the same shapes, starts
                 st.synchronize()
         for st in side:
-            cur.wait_stream(st)
+            if st != cur:
+                cur.wait_stream(st)
         return heads
 
     # ---------------------------------------------------------------- detect

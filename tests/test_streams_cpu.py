@@ -12,6 +12,7 @@ def E(monkeypatch):
 
     class FakeStream:
         def __init__(self, device=None):
+            self.q = [1, 2, 3, 3, 2, 1, 0, 3, 2, 1, 0][len(made) % 11]          # the measured hardware-queue assignment pattern
             made.append(self)
     import contextlib
     monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
@@ -58,24 +59,41 @@ def test_a_thread_keeps_its_streams_and_later_threads_inherit_the_slot(E):
     # another device has its own slots; another k its own pair inside the slot
     assert E.thread_side_streams("cuda:1", 2) is not side
     assert len(E.thread_side_streams(dev, 3)) == 3 and E.thread_side_streams(dev, 2) is side
+    # a worker that runs on its main stream keeps one sub-batch there
+    wm = E.thread_side_streams(dev, 2, with_main=True)
+    assert wm[0] is E.thread_main_stream(dev) and wm[1] is not side[0] and len(wm) == 2
 
 
 def test_candidates_that_alias_a_chosen_stream_are_set_aside(E, monkeypatch):
-    """The hardware-queue probe: a candidate that does not overlap with every chosen stream is kept alive but not used; after
-    six candidates the last one is taken as it is."""
+    """The hardware-queue probe: side streams of one thread never share a queue; aliasing candidates are kept alive but not used;
+    the main stream is not probed."""
     monkeypatch.setattr(E, "STREAM_PROBE", True)
     monkeypatch.setattr(E, "_stream_rejects", [])
     import torch
     monkeypatch.setattr(torch.cuda, "_sleep", lambda c: None, raising=False)
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
-    order = {}
-    queue_of = lambda s_: order.setdefault(id(s_), [1, 2, 3, 3, 2, 1, 0, 3][len(order) % 8])     # the measured assignment pattern
+    queue_of = lambda s_: s_.q
     monkeypatch.setattr(E, "_streams_overlap", lambda a, b: queue_of(a) != queue_of(b))
-    main = E.thread_main_stream("cuda:0")                 # queue 1
-    side = E.thread_side_streams("cuda:0", 2)             # queues 2 and 3; the 4th stream (queue 3 again) is never asked for
+    main = E.thread_main_stream("cuda:0")                 # queue 1, no probe
+    side = E.thread_side_streams("cuda:0", 2)             # queues 2 and 3
     assert [queue_of(x) for x in [main] + side] == [1, 2, 3] and not E._stream_rejects
-    more = E.thread_side_streams("cuda:0", 3)             # 3 streams beside `main` on 4 queues: 3 (alias of nothing chosen), then 2, then 0
-    assert len({queue_of(x) for x in more} | {queue_of(main)}) == 4 and len(E._stream_rejects) >= 1
+    out = {}
+
+    def second_worker():
+        out["main"] = E.thread_main_stream("cuda:0")
+        out["side"] = E.thread_side_streams("cuda:0", 2, with_main=True)
+    t = threading.Thread(target=second_worker)
+    t.start(); t.join()
+    qs = [queue_of(x) for x in out["side"]]
+    # the second worker's main is stream number 4 of the process and lands on queue 3 like the 3rd stream did; it hosts one
+    # sub-batch itself, the other goes to the next stream (queue 2): no aliasing inside the thread, nothing set aside
+    assert out["side"][0] is out["main"] and qs == [3, 2] and not E._stream_rejects
+    # a thread whose first two candidates alias (streams 3 and 4 of the pattern: both queue 3) sets one aside
+    monkeypatch.setattr(E, "_made", E._made)
+    E._made.clear(); E._made.extend([None] * 2)                                  # the next streams are numbers 3 and 4: queues 3, 3
+    pair = E._new_stream_beside("cuda:0", []), None
+    pair = (pair[0], E._new_stream_beside("cuda:0", [pair[0]]))
+    assert [queue_of(x) for x in pair] == [3, 2] and len(E._stream_rejects) == 1 and queue_of(E._stream_rejects[0]) == 3
     monkeypatch.setattr(E, "_streams_overlap", lambda a, b: False)               # everything aliases: give up after six candidates
     n0 = len(E._made)
     assert E._new_stream_beside("cuda:0", [main]) is E._made[-1] and len(E._made) - n0 == 7

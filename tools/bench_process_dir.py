@@ -32,3 +32,21 @@ with tempfile.TemporaryDirectory() as d:
     print(f"{n} jpg {size}x{size}, num_processes={nproc}, io_threads={c.io_threads}, io_processes="
           f"{(procs.readers, procs.writers) if procs is not None else 'off (threads)'}, host cores {os.cpu_count()}: "
           f"{n / dt:.1f} images/s ({len(os.listdir(dst))} crops written)")
+    if os.environ.get("FCP_STREAM_MATRIX"):                 # which of the workers' streams share a hardware queue (engine._streams_overlap)
+        import torch
+        from face_crop_plus_amd import engine as E
+        names, streams = ["D"], [torch.cuda.default_stream(c.device)]
+        for i, slot in enumerate(E._stream_sets.get(c.device.index or 0, [])):
+            if slot["main"] is not None:
+                names.append(f"w{i}.main"); streams.append(slot["main"])
+            for k, v in slot["side"].items():
+                for j, s_ in enumerate(v):
+                    names.append(f"w{i}.s{j}"); streams.append(s_)
+        groups = []
+        for nm, s_ in zip(names, streams):
+            for g in groups:
+                if not E._streams_overlap(g[0][1], s_):
+                    g.append((nm, s_)); break
+            else:
+                groups.append([(nm, s_)])
+        print("   hardware queues: " + " | ".join(",".join(nm for nm, _ in g) for g in groups))
