@@ -33,7 +33,7 @@ bash tools/profile_workload.sh c2 trace --batch 64 --size 640 > $O/profile_c2_tr
 python tools/summarize_trace.py gpurun_out/prof_c2/trace $O/${TAG}_f16x3_bench_step_trace.csv 2>&1 | tee -a $O/summarize_trace.log
 cp $(find gpurun_out/prof_c2/trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_f16x3_bench_kernel_stats.csv
 rm -rf gpurun_out/prof_c2/trace gpurun_out/prof_c2/trace2
-pmc f16x3_pmc_conv c2 64 640 "bench.py --batch 64 --size 640"
+pmc f16x3_pmc_conv c2 64 640 "bench.py --batch 64 --size 640" --batch 64 --size 640
 rm -rf gpurun_out/prof_c2
 # ---- configs[2] without RRDB, RRDB on every image (batch 2), exact-fp32 mode: counters only
 pmc c3_pmc c3 32 1024 "bench.py --workload full --enhance none" --workload full --enhance none
