@@ -124,6 +124,7 @@ def test_conv_upsampled_input(device):
     assert (out.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
 
 
+@pytest.mark.f16x3_only
 @pytest.mark.parametrize("cin,cout,hw,n", [(64, 64, (9, 11), 1), (64, 32, (20, 37), 2), (128, 128, (12, 40), 1), (64, 64, (70, 130), 2)])
 def test_conv_in_up2_halo_tiles(cin, cout, hw, n, device, precision):
     """Nearest x2 fused into the operand fetch (RRDB's upconv1 / upconv2) on the halo-tile kernels: the staged halo row of a
@@ -219,6 +220,7 @@ def test_split32_bits_vs_numpy(device):
     assert np.abs(back - x).max() <= 2.0 ** -21 * np.abs(x).max()
 
 
+@pytest.mark.f16x3_only
 @pytest.mark.parametrize("k,stride,cin,cout", [(1, 1, 64, 256), (3, 1, 128, 128), (3, 2, 64, 64), (1, 2, 256, 512)])
 def test_conv_split32_in_out_with_residual(k, stride, cin, cout, device, precision):
     """split32 activations end to end: split input, split residual, split output (fp16x3 path only)."""
@@ -245,6 +247,7 @@ def test_conv_split32_in_out_with_residual(k, stride, cin, cout, device, precisi
         assert out2.fmt == 0 and (out2.nchw().cpu() - ref).abs().max().item() <= _tol(ref)
 
 
+@pytest.mark.f16x3_only
 def test_conv_split32_channel_slices(device, precision):
     """SSH-style: read a 32-aligned channel slice of a split32 buffer, write another slice of it."""
     if precision != "f16x3":
@@ -262,6 +265,7 @@ def test_conv_split32_channel_slices(device, precision):
     assert (full[:, :256] - feat[:, :256]).abs().max().item() <= 2.0 ** -20 * feat.abs().max().item()   # untouched
 
 
+@pytest.mark.f16x3_only
 @pytest.mark.parametrize("k,stride,cin,cout,hw", [(1, 1, 64, 256, (18, 22)), (3, 1, 128, 128, (18, 22)), (3, 2, 64, 384, (19, 21)),
                                                   (1, 2, 256, 512, (18, 22)), (1, 1, 1024, 256, (9, 7)), (3, 1, 32, 200, (16, 16))])
 def test_conv_256_row_tiles(k, stride, cin, cout, hw, device, precision):
@@ -302,6 +306,7 @@ def test_conv_256_row_tiles_rejects_unsupported(device, precision):
         E.conv(pc, x, tile_m=256, tile_n=128)
 
 
+@pytest.mark.f16x3_only
 @pytest.mark.parametrize("c1,c2,cout,stride,hw", [(64, 64, 256, 1, (18, 22)), (128, 256, 512, 2, (20, 24)),
                                                   (256, 512, 1024, 2, (14, 10)), (32, 96, 72, 3, (19, 22))])
 def test_conv_two_sources(c1, c2, cout, stride, hw, device, precision):
@@ -336,6 +341,7 @@ def test_conv_two_sources(c1, c2, cout, stride, hw, device, precision):
         E.conv(pc3, xa, x2=xb, x2_stride=stride)
 
 
+@pytest.mark.f16x3_only
 @pytest.mark.parametrize("cin,cout,hw,n", [(64, 32, (16, 64), 2), (96, 32, (19, 45), 1), (160, 24, (8, 32), 3), (64, 32, (5, 7), 2),
                                            (192, 8, (33, 70), 1), (192, 64, (40, 70), 2), (64, 64, (9, 33), 1), (96, 40, (17, 20), 2),
                                            (96, 32, (256, 384), 3), (128, 64, (200, 300), 2)])
@@ -379,6 +385,7 @@ def test_conv_halo_tiles(cin, cout, hw, n, device, precision):
         E.conv(E.pack_conv(torch.randn(96, cin, 3, 3), None, None, 1, 1, device), xs, tile_m=1, tile_n=64)
 
 
+@pytest.mark.f16x3_only
 @pytest.mark.parametrize("cin,cout,hw,n", [(64, 128, (16, 64), 2), (128, 128, (19, 45), 1), (192, 96, (8, 32), 3), (64, 72, (5, 7), 2),
                                            (256, 128, (40, 70), 2), (128, 128, (200, 300), 2), (64, 64, (9, 33), 1), (128, 40, (17, 20), 2),
                                            (192, 64, (130, 260), 2)])
@@ -460,6 +467,7 @@ def test_conv_row_bands(cin, cout, hw, tiles, device, precision):
         E.conv(pc, rows(xa, 0, 12), band=(2, 0))
 
 
+@pytest.mark.f16x3_only
 @pytest.mark.parametrize("n,h,w", [(2, 77, 91), (1, 64, 64), (3, 50, 130), (1, 9, 200), (2, 640, 640)])
 def test_fused_stem_pool(n, h, w, device, precision):
     """uint8 -> (x - mean) -> 7x7/2 conv + BN + ReLU -> max-pool 3x3/2 in one launch (RetinaFace stem, fp16x3 path):
@@ -613,6 +621,7 @@ def test_conv_flat_flag_rejected_on_f16x3(device):
         E.conv(pc, E.Act(torch.zeros(1, 4, 4, 64, device=device)), flat=True)
 
 
+@pytest.mark.f16x3_only
 def test_autotune_does_not_corrupt_in_place_ops(device, precision):
     """An op whose output aliases a residual (RRDB conv5 of the third dense block: out and res2 are the same
     tensor) must give the same result whether or not its shape is being autotuned (trial launches go to scratch)."""
@@ -638,6 +647,7 @@ def test_autotune_does_not_corrupt_in_place_ops(device, precision):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.f16x3_only
 @pytest.mark.parametrize("n,h,w", [(2, 77, 91), (1, 64, 64), (3, 50, 130), (1, 9, 200), (2, 512, 512)])
 def test_fused_stem_pool_f32_input(n, h, w, device, precision):
     """Round 5: the fused stem on a normalised fp32 NHWC4 input (BiSeNet's ResNet-18 stem): conv 7x7 / 2 (BatchNorm folded) ->
