@@ -73,6 +73,12 @@ class Cropper:
         self.weights = weights or {}
         self.precision = precision   # "f16x3" (default) | "f32": arithmetic of the conv engine
         self.num_std_landmarks = 5
+        # GPU worker threads of process_dir (each runs whole batches: upload, detect, align, read-back).  The reference's
+        # `num_processes` is the size of its ThreadPool (cropper.py:900-902, default 1); here one worker leaves the device idle
+        # while it is in its host phases — 2365-2438 images/s end to end against 3148-3209 with two (profiles/r06_probes.md
+        # section 2) — so at least two batches are in flight unless told otherwise (gpu_workers = 1, or FCP_GPU_WORKERS=1).
+        # The output set does not depend on it (tests/test_cropper_gpu.py::test_process_dir_pipeline_is_deterministic).
+        self.gpu_workers = int(os.environ["FCP_GPU_WORKERS"]) if os.environ.get("FCP_GPU_WORKERS") else None
         # host I/O threads of process_dir (decode prefetch + asynchronous encode/write around the GPU workers)
         self.io_threads = max(2, min(16, (os.cpu_count() or 4) // 2))
         # ... and, by default, one decode / encode worker PROCESS behind every I/O thread (_io_pool.py): the
@@ -353,7 +359,8 @@ class Cropper:
         # encoded crops / masks are written asynchronously on the same I/O pool.  File naming, warn-and-skip
         # and the output directory layout are exactly those of the synchronous `process_batch`.
         from concurrent.futures import ThreadPoolExecutor
-        depth = max(2, 2 * self.num_processes)
+        workers = max(1, self.gpu_workers) if self.gpu_workers else max(2, self.num_processes)
+        depth = max(2, 2 * workers)
         procs = self._io_processes()
         if procs is not None:
             # one I/O thread per worker process (a thread only relays: request, blocking reply); decode and encode have
@@ -402,7 +409,7 @@ class Cropper:
             images, names, tokens = collect_read(i, futs) if futs is not None else (*read_images(file_batches[i], input_dir), [])
             pinned = procs.pinned_flags(tokens) if procs is not None and tokens else None   # images in page-locked rings
             try:
-                if self.num_processes == 1:
+                if workers == 1:
                     return self._process_images(images, names, output_dir, pinned)
                 # one HIP stream per GPU worker: the batches of different workers overlap on the device (the tail of
                 # one kernel with the head of another; measured +4 % at two streams) instead of queueing on stream 0
@@ -424,7 +431,7 @@ class Cropper:
 
         failed = True
         try:
-            with ThreadPool(self.num_processes) as pool:
+            with ThreadPool(workers) as pool:
                 imap = pool.imap(worker, range(len(file_batches)))
                 if desc is not None:
                     try:

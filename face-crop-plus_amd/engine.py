@@ -227,7 +227,7 @@ class _StreamClaim:
             pass
 
 
-_stream_lock = threading.Lock()
+_stream_lock = threading.RLock()    # re-entrant: a _StreamClaim may be finalised while its thread holds the lock
 _stream_sets: dict = {}          # device index -> [slot -> {"main": Stream | None, "side": {k: [k Streams]}}]
 _stream_free: dict = {}          # device index -> slots no living thread holds
 _stream_tls = threading.local()

@@ -180,9 +180,11 @@ def test_process_dir_pipeline_is_deterministic(tmp_path, device):
     kw = dict(output_size=64, resize_size=160, strategy="all", det_threshold=0.55, batch_size=3, device="cuda:0",
               weights={"retinaface": "generated"})
     outs = []
-    for k, (np_, io) in enumerate(((1, 2), (3, 5))):
+    for k, (np_, io, gw) in enumerate(((1, 2, 1), (3, 5, None), (1, 3, None))):     # one worker; three; the default (two for num_processes=1)
         c = Cropper(num_processes=np_, **kw)
         c.io_threads = io
+        if gw is not None:
+            c.gpu_workers = gw
         with pytest.warns(UserWarning, match="Could not read"):
             c.process_dir(str(src), str(tmp_path / f"o{k}"), desc=None)
         outs.append({f: (tmp_path / f"o{k}" / f).read_bytes() for f in sorted(os.listdir(tmp_path / f"o{k}"))})
@@ -192,7 +194,7 @@ def test_process_dir_pipeline_is_deterministic(tmp_path, device):
         for i in range(0, len(files), 3):
             c.process_batch(files[i:i + 3], str(src), str(tmp_path / "sync"))
     outs.append({f: (tmp_path / "sync" / f).read_bytes() for f in sorted(os.listdir(tmp_path / "sync"))})
-    assert len(outs[0]) > 5 and outs[0] == outs[1] == outs[2]
+    assert len(outs[0]) > 5 and outs[0] == outs[1] == outs[2] == outs[3]
 
 
 def test_crop_align_plumbing_like_reference(device):

@@ -18,6 +18,7 @@ with tempfile.TemporaryDirectory() as d:
     for i in range(n):
         Image.fromarray(np.roll(img, i, 1)).save(os.path.join(src, f"{i:05d}.jpg"), quality=90)
     c = Cropper(resize_size=size, batch_size=64, num_processes=nproc, device="cuda:0", weights={"retinaface": "generated"})
+    c.gpu_workers = nproc                                     # exactly nproc GPU worker threads (the product default: max(2, num_processes))
     if io:
         c.io_threads = io
     if os.environ.get("FCP_IO_PROCS"):                      # "readers,writers"
