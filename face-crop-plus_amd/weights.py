@@ -194,6 +194,41 @@ def generate_state_dict(model: str, seed: int = 0, as_torch: bool = True):
     return out
 
 
+def trained_like_statistics(sd, seed: int = 0, bn_decades: float = 1.5, outlier_fraction: float = 1e-3, outlier_scale: float = 6.0):
+    """Steps 1 and 2 of ``trained_like_retinaface`` on ANY of the three networks' state dicts (reference key names): every
+    conv -> BatchNorm pair scaled per output channel by 10^U(-d, d) (weights, ``running_mean``, ``running_var`` x s^2: exactly
+    function-preserving but for BatchNorm's eps) and a fraction of every conv filter's entries multiplied by ``outlier_scale``.
+    BatchNorm partners by name: ``...convN`` -> ``...bnN`` (ResNet blocks, stems), ``....0`` -> ``....1`` (downsample, FPN, SSH),
+    ``....conv`` -> ``....bn`` (BiSeNet's ConvBNReLU), ``...conv_atten`` -> ``...bn_atten`` (its attention modules).  RRDBNet has no
+    BatchNorm: only the heavy tails apply.  Returns a new dict of torch tensors."""
+    import torch
+    rng = np.random.default_rng(0x7A1ED + seed)
+    out = {k: torch.as_tensor(v).clone() for k, v in sd.items()}
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    convs = [k[:-len(".weight")] for k in out if k.endswith(".weight") and out[k].ndim == 4]
+    bn_of = {}
+    for conv in convs:
+        head, _, tail = conv.rpartition(".")
+        for cand in ((head + ".bn" + tail[4:]) if tail.startswith("conv") and tail[4:].isdigit() else None,
+                     (head + ".1") if tail == "0" else None,
+                     (head + ".bn") if tail == "conv" else None,
+                     (head + ".bn_atten") if tail == "conv_atten" else None):
+            if cand and (cand + ".running_var") in out and out[cand + ".running_var"].shape[0] == out[conv + ".weight"].shape[0]:
+                bn_of[conv] = cand
+                break
+    for conv, bn in bn_of.items():
+        w = out[conv + ".weight"]
+        s = f32(10.0 ** rng.uniform(-bn_decades, bn_decades, w.shape[0]))
+        out[conv + ".weight"] = w * s[:, None, None, None]
+        out[bn + ".running_mean"] = out[bn + ".running_mean"] * s
+        out[bn + ".running_var"] = out[bn + ".running_var"] * s * s
+    for conv in convs:
+        w = out[conv + ".weight"]
+        hit = f32(rng.random(tuple(w.shape)) < outlier_fraction)
+        out[conv + ".weight"] = w * (1 + (outlier_scale - 1) * hit)
+    return out
+
+
 def trained_like_retinaface(sd, seed: int = 0, stream_gain=(10.0, 30.0, 100.0, 10.0), uniform_gain: bool = False,
                            bn_decades: float = 1.5, outlier_fraction: float = 1e-3, outlier_scale: float = 6.0):
     """A RetinaFace state dict with the statistics of a TRAINED checkpoint, derived from ``sd`` (normally the generated one).
@@ -211,29 +246,11 @@ def trained_like_retinaface(sd, seed: int = 0, stream_gain=(10.0, 30.0, 100.0, 1
        (the following conv1 / downsample.0 / fpn.output) input channel divided by k — exactly function-preserving for
        k > 0 since ReLU is positively homogeneous; the stream's activations reach gain x their former size.
 
-    Returns a new dict of torch tensors (``sd`` is not modified)."""
+    Steps 1 and 2 are ``trained_like_statistics`` (any of the three networks).  Returns a new dict of torch tensors (``sd`` is not modified)."""
     import torch
-    rng = np.random.default_rng(0x7A1ED + seed)
-    out = {k: torch.as_tensor(v).clone() for k, v in sd.items()}
+    out = trained_like_statistics(sd, seed, bn_decades, outlier_fraction, outlier_scale)
+    rng = np.random.default_rng(0x57EA4 + seed)
     f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-    pairs = [(k[:-len(".weight")], None) for k in out if k.endswith(".weight") and out[k].ndim == 4]
-    bn_of = {}
-    for conv, _ in pairs:                                      # conv name -> its BatchNorm's name
-        head, _, tail = conv.rpartition(".")
-        if tail.startswith("conv") and (head + ".bn" + tail[4:] + ".running_var") in out:
-            bn_of[conv] = head + ".bn" + tail[4:]              # body.*.convN -> bnN, body.conv1 -> body.bn1
-        elif tail == "0" and (head + ".1.running_var") in out:
-            bn_of[conv] = head + ".1"                          # downsample.0/.1, fpn.*.0/.1, ssh*.0/.1
-    for conv, bn in bn_of.items():
-        w = out[conv + ".weight"]
-        s = f32(10.0 ** rng.uniform(-bn_decades, bn_decades, w.shape[0]))
-        out[conv + ".weight"] = w * s[:, None, None, None]
-        out[bn + ".running_mean"] = out[bn + ".running_mean"] * s
-        out[bn + ".running_var"] = out[bn + ".running_var"] * s * s
-    for conv, _ in pairs:
-        w = out[conv + ".weight"]
-        hit = f32(rng.random(tuple(w.shape)) < outlier_fraction)
-        out[conv + ".weight"] = w * (1 + (outlier_scale - 1) * hit)
     blocks = (3, 4, 6, 3)
     for li, gain in enumerate(stream_gain, 1):
         c = 256 * 2 ** (li - 1)

@@ -176,3 +176,54 @@ def test_trained_like_checkpoint_rehearsal(device, tmp_path, monkeypatch):
     monkeypatch.setenv("FCP_SELFCHECK", "1")
     with pytest.raises(FloatingPointError, match=r"2\^15"):      # strict mode: an error, not a fallback
         RetinaFace("largest", 0.6).load(device, str(tmp_path / "big.pth"))
+
+
+def test_trained_like_rehearsal_bisenet_and_rrdb(device, tmp_path, monkeypatch):
+    """The same rehearsal for the other two networks (``weights.trained_like_statistics``: BatchNorm variance over six decades where
+    there is BatchNorm, heavy-tailed filters everywhere), through ``load`` from a file: the guard stays silent, BiSeNet's label maps
+    differ from the oracle's on the same weights only inside fp32 summation-order noise, RRDB's enhanced bytes only at rounding
+    boundaries."""
+    import warnings
+    import torch.nn.functional as F
+    from face_crop_plus_amd import weights
+    from face_crop_plus_amd.bise import BiSeNet
+    from face_crop_plus_amd.rrdb import RRDBNet
+    from oracle import bisenet_ref as B, rrdb_ref as RR
+    monkeypatch.delenv("FCP_SELFCHECK", raising=False)
+    sb = weights.trained_like_statistics(weights.generate_state_dict("bisenet"), 2)
+    rv = torch.cat([v.flatten() for k, v in sb.items() if k.endswith("running_var")])
+    assert float(rv.min()) < 2e-3 and float(rv.max()) > 5e2
+    torch.save(sb, tmp_path / "bise.pth")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        par = BiSeNet(None, None, 4).load(device, str(tmp_path / "bise.pth"))
+    rep = par.selfcheck_report
+    print("BiSeNet trained-like: peak |x|", max(v for _, v in rep["launch_absmax"]), "logit rel diff", rep["logit_rel_diff"])
+    assert par.precision == 1 and rep["logit_rel_diff"] < 1e-4
+    g = torch.Generator().manual_seed(12)
+    faces = torch.randint(0, 256, (2, 160, 192, 3), generator=g, dtype=torch.uint8)
+    labels, _ = par.parse(faces.to(device))
+    with torch.no_grad():
+        x = faces.permute(0, 3, 1, 2).float()
+        logits = F.interpolate(B.forward(B.preprocess(x), sb), size=x.shape[2:], mode="nearest")
+    top2 = logits.topk(2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1]).numpy()
+    mism = labels.cpu().numpy() != logits.argmax(1).numpy()
+    scale = float(logits.abs().max())
+    print("trained-like label mismatches:", int(mism.sum()), "of", mism.size, "largest oracle margin at a mismatch:",
+          float(gap[mism].max()) if mism.any() else 0.0, "logit scale", scale)
+    assert (gap[mism] < 1e-4 * max(1.0, scale)).all() and mism.mean() < 2e-3
+    se = weights.trained_like_statistics(weights.generate_state_dict("rrdb"), 3)
+    torch.save(se, tmp_path / "rrdb.pth")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        enh = RRDBNet(1.0).load(device, str(tmp_path / "rrdb.pth"))
+    rep = enh.selfcheck_report
+    print("RRDB heavy-tailed: peak |x|", max(v for _, v in rep["launch_absmax"]), "output rel diff", rep["output_rel_diff"])
+    assert enh.precision == 1 and rep["output_rel_diff"] < 1e-4
+    img = torch.randint(0, 256, (1, 96, 80, 3), generator=g, dtype=torch.uint8)
+    ref = RR.predict(img.permute(0, 3, 1, 2).float(), se, None, None).permute(0, 2, 3, 1).numpy()
+    got = enh.predict(img.to(device), None, None).cpu().numpy()
+    diff = np.abs(got.astype(int) - ref.astype(int))
+    print("RRDB heavy-tailed vs oracle: max", diff.max(), "differing bytes", float((diff > 0).mean()))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
