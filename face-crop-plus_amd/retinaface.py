@@ -46,7 +46,7 @@ class RetinaFace:
         # conv2 + conv3 of an identity bottleneck and conv1 of the next block in one launch (layer 1; bit-identical)
         self.fused_chain = os.environ.get("FCP_FUSED_CHAIN", "1") != "0"
         self.streams = int(os.environ.get("FCP_DET_STREAMS", "2"))
-        self.min_images_per_stream = 8
+        self.min_images_per_stream = 6      # tools/probe_min_images_per_stream.py: batch 8 is best on one stream (1210 vs 1165 faces/s), batch 12 on two (1308 vs 1288)
         self.split_cu_budget = os.environ.get("FCP_SPLIT_CU_BUDGET", "1") != "0"
         self._tls = threading.local()
 
