@@ -76,7 +76,7 @@ class Cropper:
         # GPU worker threads of process_dir (each runs whole batches: upload, detect, align, read-back).  The reference's
         # `num_processes` is the size of its ThreadPool (cropper.py:900-902, default 1); here one worker leaves the device idle
         # while it is in its host phases — 2365-2438 images/s end to end against 3148-3209 with two (profiles/r06_probes.md
-        # section 2) — so at least two batches are in flight unless told otherwise (gpu_workers = 1, or FCP_GPU_WORKERS=1).
+        # section 2) — so at least two batches (three for batch_size <= 8) are in flight unless told otherwise (gpu_workers = 1, or FCP_GPU_WORKERS=1).
         # The output set does not depend on it (tests/test_cropper_gpu.py::test_process_dir_pipeline_is_deterministic).
         self.gpu_workers = int(os.environ["FCP_GPU_WORKERS"]) if os.environ.get("FCP_GPU_WORKERS") else None
         # host I/O threads of process_dir (decode prefetch + asynchronous encode/write around the GPU workers)
@@ -359,7 +359,9 @@ class Cropper:
         # encoded crops / masks are written asynchronously on the same I/O pool.  File naming, warn-and-skip
         # and the output directory layout are exactly those of the synchronous `process_batch`.
         from concurrent.futures import ThreadPoolExecutor
-        workers = max(1, self.gpu_workers) if self.gpu_workers else max(2, self.num_processes)
+        # small batches (the reference's default batch_size = 8) leave the device idle even with two in flight: 1264-1282 images/s
+        # end to end with three workers against 1086-1258 with two (batch 8 @1024^2), while batch 32 prefers two (1357-1368 against 1261-1289)
+        workers = max(1, self.gpu_workers) if self.gpu_workers else max(3 if self.batch_size <= 8 else 2, self.num_processes)
         depth = max(2, 2 * workers)
         procs = self._io_processes()
         if procs is not None:

@@ -17,7 +17,7 @@ with tempfile.TemporaryDirectory() as d:
     img = np.asarray(Image.fromarray(base).resize((size, size), Image.BICUBIC))
     for i in range(n):
         Image.fromarray(np.roll(img, i, 1)).save(os.path.join(src, f"{i:05d}.jpg"), quality=90)
-    c = Cropper(resize_size=size, batch_size=64, num_processes=nproc, device="cuda:0", weights={"retinaface": "generated"})
+    c = Cropper(resize_size=size, batch_size=int(os.environ.get("FCP_BENCH_BATCH", "64")), num_processes=nproc, device="cuda:0", weights={"retinaface": "generated"})
     c.gpu_workers = nproc                                     # exactly nproc GPU worker threads (the product default: max(2, num_processes))
     if io:
         c.io_threads = io
